@@ -1,0 +1,67 @@
+"""ctypes binding of libdeephisto_hip.so (the C ABI declared in include/deephisto_hip.h).
+
+There is no CPU fallback: if the library is missing, or a call fails, this
+module raises.  The library is built in-tree by deephisto_amd.build.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libdeephisto_hip.so"
+
+DH_LAYOUT_NHWC, DH_LAYOUT_NCHW = 0, 1
+DH_DTYPE_F32, DH_DTYPE_BF16 = 0, 1
+
+_i32, _i64, _u32 = C.c_int32, C.c_int64, C.c_uint32
+_p = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/deephisto_hip.h
+SIGNATURES = {
+    "dh_abi_version": (C.c_int, []),
+    "dh_last_error": (C.c_char_p, []),
+    "dh_tile_grid_count": (C.c_int, [_i64, _i64, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "dh_tile_grid": (C.c_int, [_i64, _i64, _i32, _i32, _i32, _p, _i64]),
+    "dh_synth_slide": (C.c_int, [_p, _i64, _i64, _u32, _p]),
+    "dh_tile_gather": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    "dh_tile_coords_f32": (C.c_int, [_p, _i64, _p, _p]),
+    "dh_accumulate_logits": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i64, _i64, _p, _p, _p]),
+    "dh_argmax_map": (C.c_int, [_p, _i64, _i32, _p, _p]),
+    "dh_resnet18_create": (C.c_int, [C.POINTER(_p), _i32, _i32]),
+    "dh_resnet18_destroy": (None, [_p]),
+    "dh_resnet18_set_param": (C.c_int, [_p, C.c_char_p, _p, _i64]),
+    "dh_resnet18_finalize": (C.c_int, [_p, _p]),
+    "dh_resnet18_forward": (C.c_int, [_p, _p, _i64, _i32, _p, _p]),
+    "dh_resnet18_forward_tiles": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _p, _p]),
+    "dh_debug_conv_bn_act": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i32] * 9 + [_p]),
+    "dh_debug_stem_out": (C.c_int, [_p, _i64, _i32, _p, _p]),
+}
+
+
+class DeephistoHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise DeephistoHipError(
+                f"{LIB_PATH} is missing: build it with `python -m deephisto_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+        h = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().dh_last_error()
+        raise DeephistoHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,892 @@
+// ResNet-18 patch-classifier forward for MI355X (gfx950), hand-written HIP.
+//
+// Replaces `model(features)` of the network built by
+// models/patch_cls_simple/model.py:5-11 (torchvision resnet18 + fc[n_cls,512]) as
+// called from examples/predict_full_patched.py:77 (eval mode).
+//
+// Design (see DESIGN.md section "a6"):
+//  * activations live in HBM as NHWC ("pixel-major") so the reduction index of
+//    every convolution, (tap, cin), is contiguous in cin: a 64-byte channel chunk
+//    of one pixel is one LDS row, and a lane's MFMA B-fragment is one 16-byte read;
+//  * each conv is an implicit GEMM  D[cout][pixel] = sum_k W[cout][k] * X[k][pixel]
+//    on v_mfma_f32_32x32x16_bf16 (bf16 mode) or v_mfma_f32_32x32x2_f32 (f32 mode,
+//    exact f32 products, used for the 1e-4 parity runs).  cout is the MFMA row
+//    index so every lane ends up with 4 consecutive couts of one pixel -> 8/16-byte
+//    NHWC stores with BN scale/shift, residual add and ReLU fused in the epilogue;
+//  * a workgroup (4 waves) owns 64 couts x 256 pixels (a 16x16 patch of one image,
+//    or 8x8 patches of 4 images).  For 3x3/stride-1 convs (85 % of the FLOPs) the
+//    input patch plus its 1-pixel halo is staged in LDS ONCE per 64-byte channel
+//    chunk and all 9 taps read shifted windows of it (LDS-staged im2col);
+//    stride-2 and 1x1 convs stage one tap at a time;
+//  * weights are pre-packed on the host in MFMA fragment order, so staging them is
+//    a linear 16-byte copy and reading them is conflict-free `base + lane*16`;
+//  * LDS per workgroup <= 68 KiB and <= 128 VGPRs -> two workgroups per CU, one
+//    staging while the other issues MFMAs.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dh_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int CHUNK_BYTES = 64;   // channel bytes of one pixel staged per pass
+constexpr int PIX_PITCH = 80;     // LDS bytes per staged pixel (64 + 16 pad: bank spread)
+constexpr int FRAG_BYTES = 1024;  // one MFMA operand fragment: 64 lanes x 16 B
+constexpr int SLAB_TAP = 4 * FRAG_BYTES;  // per tap: 2 k-steps x 2 cout-tiles
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int ESZ = 4; };
+template <> struct ElemTraits<__bf16> { static constexpr int ESZ = 2; };
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float div255f(uint32_t k) {
+  const float r = 1.0f / 255.0f;
+  const float kf = (float)k;
+  const float q = kf * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, kf), r, q);
+}
+
+template <typename T>
+__device__ __forceinline__ void mma_frag(f32x16& acc, const uint4& a, const uint4& b) {
+  if constexpr (sizeof(T) == 2) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                  __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+}
+
+// Epilogue shared by stem and conv kernels.  acc[mt][nt] holds D[cout][pixel]:
+// lane: pixel = lane&31 of n-tile nt; register r: cout = 32*mt + (r&3) + 8*(r>>2) + 4*(lane>>5).
+// y = acc*scale + shift (+ residual) (ReLU) -> 4 consecutive couts per store.
+template <typename T>
+__device__ __forceinline__ void store_group(const f32x16& acc, int g, const float* __restrict__ scale,
+                                            const float* __restrict__ shift, const T* __restrict__ res,
+                                            T* __restrict__ out, int64_t off, int co, bool relu) {
+  const float4 sc = *reinterpret_cast<const float4*>(scale + co);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + co);
+  float v[4] = {__builtin_fmaf(acc[4 * g + 0], sc.x, sh.x), __builtin_fmaf(acc[4 * g + 1], sc.y, sh.y),
+                __builtin_fmaf(acc[4 * g + 2], sc.z, sh.z), __builtin_fmaf(acc[4 * g + 3], sc.w, sh.w)};
+  if (res) {
+    if constexpr (sizeof(T) == 2) {
+      const uint2 r = *reinterpret_cast<const uint2*>(res + off);
+      v[0] += bf16_bits_to_f32(r.x & 0xFFFFu); v[1] += bf16_bits_to_f32(r.x >> 16);
+      v[2] += bf16_bits_to_f32(r.y & 0xFFFFu); v[3] += bf16_bits_to_f32(r.y >> 16);
+    } else {
+      const float4 r = *reinterpret_cast<const float4*>(res + off);
+      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+  }
+  if (relu) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+  }
+  if constexpr (sizeof(T) == 2) {
+    uint2 w;
+    w.x = f32_to_bf16(v[0]) | (f32_to_bf16(v[1]) << 16);
+    w.y = f32_to_bf16(v[2]) | (f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2*>(out + off) = w;
+  } else {
+    *reinterpret_cast<float4*>(out + off) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Generic conv (KS x KS, stride STRIDE, pad KS/2), NHWC, Cin % (64/ESZ) == 0,
+// Cout % 64 == 0.  HALO (3x3, stride 1 only): stage patch+halo once per chunk.
+// ---------------------------------------------------------------------------
+struct ConvParams {
+  const void* in; const void* w; const float* scale; const float* shift; const void* res; void* out;
+  int B, Hi, Wi, Cin, Ho, Wo, Cout;
+  int TH, TW, IMGS;       // output patch per workgroup: IMGS images x TH x TW = 256 pixels
+  int tiles_y, tiles_x;   // patches per image
+  int relu;
+};
+
+constexpr int MAX_HALO_PIECES = 7;  // ceil(4 * IMGS*(TH+2)*(TW+2) / 256), worst case 4*400/256
+
+template <typename T, int KS, int STRIDE, bool HALO>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
+  static_assert(!HALO || (KS == 3 && STRIDE == 1), "halo staging is for 3x3 stride 1");
+  constexpr int ESZ = ElemTraits<T>::ESZ;
+  constexpr int CPC = CHUNK_BYTES / ESZ;  // channels per chunk
+  constexpr int TAPS = KS * KS, PAD = KS / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* w_lds = smem;
+  char* a_lds = smem + TAPS * SLAB_TAP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = p.Cout >> 6;
+  const int cb = blockIdx.x % ncb, pt = blockIdx.x / ncb;
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const int img0 = (pt / tiles_per_img) * p.IMGS;
+  const int tile = pt % tiles_per_img;
+  const int oy0 = (tile / p.tiles_x) * p.TH, ox0 = (tile % p.tiles_x) * p.TW;
+  const int nchunks = p.Cin / CPC;
+  const int HW2 = p.TW + 2, HH2 = p.TH + 2;
+  const char* in = static_cast<const char*>(p.in);
+
+  // this lane's two pixels (one per n-tile)
+  int pimg[2], poy[2], pox[2], b_off[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int pidx = wave * 64 + nt * 32 + (lane & 31);
+    const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
+    const int ty = rem / p.TW, tx = rem % p.TW;
+    pimg[nt] = img0 + img; poy[nt] = oy0 + ty; pox[nt] = ox0 + tx;
+    b_off[nt] = (HALO ? ((img * HH2 + ty) * HW2 + tx) : pidx) * PIX_PITCH + 16 * (lane >> 5);
+  }
+
+  // staging descriptors (global byte offset at chunk 0, LDS byte offset); -1 = zero fill
+  uint32_t g_off[MAX_HALO_PIECES];
+  int l_off[MAX_HALO_PIECES];
+  bool g_ok[MAX_HALO_PIECES];
+  const int n_pieces = HALO ? p.IMGS * HH2 * HW2 * 4 : 0;
+  if constexpr (HALO) {
+#pragma unroll
+    for (int j = 0; j < MAX_HALO_PIECES; ++j) {
+      const int i = tid + j * 256;
+      const int hp = i >> 2, q = i & 3;
+      const int img = hp / (HH2 * HW2), r = hp % (HH2 * HW2);
+      const int iy = oy0 + r / HW2 - 1, ix = ox0 + r % HW2 - 1, b = img0 + img;
+      g_ok[j] = i < n_pieces && b < p.B && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+      g_off[j] = (uint32_t)((((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Cin * ESZ + q * 16);
+      l_off[j] = i < n_pieces ? hp * PIX_PITCH + q * 16 : -1;
+    }
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const char* wsrc = static_cast<const char*>(p.w) + (int64_t)cb * nchunks * TAPS * SLAB_TAP;
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();  // previous chunk's LDS reads are done
+    // weights: linear copy of the fragment-ordered slab
+    for (int i = tid * 16; i < TAPS * SLAB_TAP; i += 256 * 16)
+      *reinterpret_cast<uint4*>(w_lds + i) =
+          *reinterpret_cast<const uint4*>(wsrc + (int64_t)ch * TAPS * SLAB_TAP + i);
+    if constexpr (HALO) {
+#pragma unroll
+      for (int j = 0; j < MAX_HALO_PIECES; ++j) {
+        if (l_off[j] >= 0) {
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (g_ok[j]) v = *reinterpret_cast<const uint4*>(in + g_off[j] + ch * CHUNK_BYTES);
+          *reinterpret_cast<uint4*>(a_lds + l_off[j]) = v;
+        }
+      }
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int kh = tap / KS, kw = tap % KS;
+      if constexpr (!HALO) {
+        if (tap > 0) __syncthreads();  // previous tap's reads done before overwrite
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = tid + j * 256;
+          const int pidx = i >> 2, q = i & 3;
+          const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
+          const int oy = oy0 + rem / p.TW, ox = ox0 + rem % p.TW, b = img0 + img;
+          const int iy = oy * STRIDE + kh - PAD, ix = ox * STRIDE + kw - PAD;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (b < p.B && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)
+            v = *reinterpret_cast<const uint4*>(
+                in + (((int64_t)b * p.Hi + iy) * p.Wi + ix) * p.Cin * ESZ + ch * CHUNK_BYTES + q * 16);
+          *reinterpret_cast<uint4*>(a_lds + pidx * PIX_PITCH + q * 16) = v;
+        }
+      }
+      if (!HALO || tap == 0) __syncthreads();
+      const int tap_off = HALO ? (kh * HW2 + kw) * PIX_PITCH : 0;
+      const char* wt = w_lds + tap * SLAB_TAP + lane * 16;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint4 a0 = *reinterpret_cast<const uint4*>(wt + (ks * 2 + 0) * FRAG_BYTES);
+        const uint4 a1 = *reinterpret_cast<const uint4*>(wt + (ks * 2 + 1) * FRAG_BYTES);
+        const uint4 b0 = *reinterpret_cast<const uint4*>(a_lds + b_off[0] + tap_off + ks * 32);
+        const uint4 b1 = *reinterpret_cast<const uint4*>(a_lds + b_off[1] + tap_off + ks * 32);
+        mma_frag<T>(acc[0][0], a0, b0);
+        mma_frag<T>(acc[0][1], a0, b1);
+        mma_frag<T>(acc[1][0], a1, b0);
+        mma_frag<T>(acc[1][1], a1, b1);
+      }
+    }
+  }
+
+  // epilogue
+  const T* res = static_cast<const T*>(p.res);
+  T* out = static_cast<T*>(p.out);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    if (pimg[nt] < p.B && poy[nt] < p.Ho && pox[nt] < p.Wo) {
+      const int64_t pix = ((int64_t)pimg[nt] * p.Ho + poy[nt]) * p.Wo + pox[nt];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = cb * 64 + mt * 32 + g * 8 + 4 * (lane >> 5);
+          store_group<T>(acc[mt][nt], g, p.scale, p.shift, res, out, pix * p.Cout + co, co, p.relu != 0);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Stem: conv 7x7 / stride 2 / pad 3, 3 -> 64, + BN + ReLU, output NHWC.
+// Source is either the model input float32 NCHW [n,3,P,P] (SRC_NCHW) or the uint8
+// HWC slide plus tile origins (SRC_U8: gather and /255 fused, a2+a5+a6).
+// Workgroup = 64 couts x (8 x 32 output pixels).  The 21 x 69 input window is
+// staged in LDS in HWC element order, normalised; a tap row kh contributes a
+// 32-wide (bf16) / 22-wide (f32) k-slice: slot 0 and the slots past 21 carry zero
+// weights, which keeps every fragment read 4-byte aligned (element 6*tx + i).
+// ---------------------------------------------------------------------------
+constexpr int STEM_TH = 8, STEM_TW = 32;
+constexpr int STEM_ROWS = 2 * STEM_TH + 5;   // 21 input rows
+constexpr int STEM_ROWE = 224;               // elements per staged row (>= 6*31 + 32)
+constexpr int STEM_REAL = 1 + 3 * (2 * STEM_TW + 5);  // 208 meaningful elements (slot 0 = dummy)
+constexpr int STEM_KW_BF16 = 32, STEM_KW_F32 = 22;    // k-slice width per tap row
+
+struct StemParams {
+  const float* x_nchw; const uint8_t* slide; const int32_t* yx; int64_t row_bytes;
+  const void* w; const float* scale; const float* shift; void* out;
+  int B, P, Ho, Wo, tiles_y, tiles_x;
+};
+
+template <typename T, bool SRC_U8>
+__global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
+  constexpr int ESZ = ElemTraits<T>::ESZ;
+  constexpr int W_BYTES = (ESZ == 2) ? 7 * 2 * 2 * FRAG_BYTES : 7 * 11 * 2 * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* w_lds = smem;
+  T* e_lds = reinterpret_cast<T*>(smem + W_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const int b = blockIdx.x / tiles_per_img, tile = blockIdx.x % tiles_per_img;
+  const int oy0 = (tile / p.tiles_x) * STEM_TH, ox0 = (tile % p.tiles_x) * STEM_TW;
+  const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+
+  for (int i = tid * 16; i < W_BYTES; i += 256 * 16)
+    *reinterpret_cast<uint4*>(w_lds + i) = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.w) + i);
+
+  int ty0 = 0, tx0 = 0;
+  if constexpr (SRC_U8) { ty0 = p.yx[2 * b]; tx0 = p.yx[2 * b + 1]; }
+  for (int i = tid; i < STEM_ROWS * STEM_ROWE; i += 256) {
+    const int r = i / STEM_ROWE, e = i % STEM_ROWE;
+    float v = 0.f;
+    if (e >= 1 && e < STEM_REAL) {
+      const int q = e - 1, ix = ix0 + q / 3, c = q % 3, iy = iy0 + r;
+      if (iy >= 0 && iy < p.P && ix >= 0 && ix < p.P) {
+        if constexpr (SRC_U8)
+          v = div255f(p.slide[(int64_t)(ty0 + iy) * p.row_bytes + (int64_t)(tx0 + ix) * 3 + c]);
+        else
+          v = p.x_nchw[(((int64_t)b * 3 + c) * p.P + iy) * p.P + ix];
+      }
+    }
+    if constexpr (ESZ == 2) reinterpret_cast<uint16_t*>(e_lds)[i] = (uint16_t)f32_to_bf16(v);
+    else e_lds[i] = v;
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int tx = lane & 31, h = lane >> 5;
+  // n-tile nt = output row ty = 2*wave + nt; input row for tap row kh: 2*ty + kh
+#pragma unroll 1
+  for (int kh = 0; kh < 7; ++kh) {
+    if constexpr (ESZ == 2) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const char* wt = w_lds + ((kh * 2 + t) * 2) * FRAG_BYTES + lane * 16;
+        const uint4 a0 = *reinterpret_cast<const uint4*>(wt);
+        const uint4 a1 = *reinterpret_cast<const uint4*>(wt + FRAG_BYTES);
+        uint4 bb[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int row = 2 * (2 * wave + nt) + kh;
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(
+              reinterpret_cast<const char*>(e_lds) + (row * STEM_ROWE + 6 * tx + 16 * t + 8 * h) * 2);
+          bb[nt] = make_uint4(src[0], src[1], src[2], src[3]);
+        }
+        mma_frag<T>(acc[0][0], a0, bb[0]);
+        mma_frag<T>(acc[0][1], a0, bb[1]);
+        mma_frag<T>(acc[1][0], a1, bb[0]);
+        mma_frag<T>(acc[1][1], a1, bb[1]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 11; ++s) {
+        const float* wt = reinterpret_cast<const float*>(w_lds) + ((kh * 11 + s) * 2) * 64 + lane;
+        const float a0 = wt[0], a1 = wt[64];
+        float bv[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int row = 2 * (2 * wave + nt) + kh;
+          bv[nt] = reinterpret_cast<const float*>(e_lds)[row * STEM_ROWE + 6 * tx + 2 * s + h];
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[1], acc[1][1], 0, 0, 0);
+      }
+    }
+  }
+
+  T* out = static_cast<T*>(p.out);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int oy = oy0 + 2 * wave + nt, ox = ox0 + tx;
+    if (oy < p.Ho && ox < p.Wo) {
+      const int64_t pix = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = mt * 32 + g * 8 + 4 * h;
+          store_group<T>(acc[mt][nt], g, p.scale, p.shift, (const T*)nullptr, out, pix * 64 + co, co, true);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// maxpool 3x3 / stride 2 / pad 1, NHWC; one thread = 16 bytes of channels.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                      int B, int Hi, int Wi, int C, int Ho, int Wo) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  const int cv = C / EPV;
+  const int64_t total = (int64_t)B * Ho * Wo * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv);
+    int64_t r = i / cv;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float m[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = 2 * oy + dy - 1;
+      if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = 2 * ox + dx - 1;
+        if (ix < 0 || ix >= Wi) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(in + (((int64_t)b * Hi + iy) * Wi + ix) * C + c * EPV);
+        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            m[2 * e] = fmaxf(m[2 * e], bf16_bits_to_f32(u[e] & 0xFFFFu));
+            m[2 * e + 1] = fmaxf(m[2 * e + 1], bf16_bits_to_f32(u[e] >> 16));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], __uint_as_float(u[e]));
+        }
+      }
+    }
+    uint4 o;
+    if constexpr (sizeof(T) == 2) {
+      o.x = f32_to_bf16(m[0]) | (f32_to_bf16(m[1]) << 16); o.y = f32_to_bf16(m[2]) | (f32_to_bf16(m[3]) << 16);
+      o.z = f32_to_bf16(m[4]) | (f32_to_bf16(m[5]) << 16); o.w = f32_to_bf16(m[6]) | (f32_to_bf16(m[7]) << 16);
+    } else {
+      o = make_uint4(__float_as_uint(m[0]), __float_as_uint(m[1]), __float_as_uint(m[2]), __float_as_uint(m[3]));
+    }
+    *reinterpret_cast<uint4*>(out + i * EPV) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// global average pool + fc: one workgroup per image; f32 arithmetic.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fc_kernel(const T* __restrict__ in, int HW, int C,
+                                                         const float* __restrict__ fc_w,
+                                                         const float* __restrict__ fc_b, int n_cls,
+                                                         float* __restrict__ logits) {
+  __shared__ float pooled[512];
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float inv = 1.0f / (float)HW;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int q = 0; q < HW; ++q) {
+      if constexpr (sizeof(T) == 2)
+        s += bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(in)[((int64_t)b * HW + q) * C + c]);
+      else
+        s += in[((int64_t)b * HW + q) * C + c];
+    }
+    pooled[c] = s * inv;
+  }
+  __syncthreads();
+  for (int k = 0; k < n_cls; ++k) {
+    float s = 0.f;
+    for (int c = tid; c < C; c += 256) s = __builtin_fmaf(pooled[c], fc_w[k * C + c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) logits[(int64_t)b * n_cls + k] = red[0] + red[1] + red[2] + red[3] + fc_b[k];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct ConvLayer {
+  std::string name;  // state_dict prefix of the conv ("layer1.0.conv1"); BN is its sibling
+  std::string bn;
+  int cin, cout, ks, stride;
+  void* w_dev = nullptr;        // packed weights
+  float* scale_dev = nullptr;   // [cout]
+  float* shift_dev = nullptr;
+};
+
+inline uint16_t host_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x7FFFFFu)) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+}  // namespace
+
+struct dh_resnet18 {
+  int n_classes = 0;
+  int dtype = DH_DTYPE_F32;
+  std::map<std::string, std::vector<float>> params;  // host copies by state_dict name
+  std::vector<ConvLayer> convs;                      // index 0 = stem
+  float* fc_w_dev = nullptr;
+  float* fc_b_dev = nullptr;
+  bool finalized = false;
+  // activation workspace
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  int esz() const { return dtype == DH_DTYPE_F32 ? 4 : 2; }
+};
+
+namespace {
+
+void build_topology(dh_resnet18* net) {
+  net->convs.clear();
+  net->convs.push_back({"conv1", "bn1", 3, 64, 7, 2});
+  const int ch[4] = {64, 128, 256, 512};
+  int cin = 64;
+  for (int s = 0; s < 4; ++s) {
+    for (int blk = 0; blk < 2; ++blk) {
+      const std::string pre = "layer" + std::to_string(s + 1) + "." + std::to_string(blk);
+      const int stride = (blk == 0 && s > 0) ? 2 : 1;
+      const int bcin = blk == 0 ? cin : ch[s];
+      net->convs.push_back({pre + ".conv1", pre + ".bn1", bcin, ch[s], 3, stride});
+      net->convs.push_back({pre + ".conv2", pre + ".bn2", ch[s], ch[s], 3, 1});
+      if (blk == 0 && s > 0)
+        net->convs.push_back({pre + ".downsample.0", pre + ".downsample.1", bcin, ch[s], 1, 2});
+    }
+    cin = ch[s];
+  }
+}
+
+int64_t expected_elems(const dh_resnet18* net, const std::string& name) {
+  if (name == "fc.weight") return (int64_t)net->n_classes * 512;
+  if (name == "fc.bias") return net->n_classes;
+  for (const auto& c : net->convs) {
+    if (name == c.name + ".weight") return (int64_t)c.cout * c.cin * c.ks * c.ks;
+    for (const char* s : {".weight", ".bias", ".running_mean", ".running_var"})
+      if (name == c.bn + s) return c.cout;
+    if (name == c.bn + ".num_batches_tracked") return 1;
+  }
+  return -1;
+}
+
+// Pack [cout][cin][ks][ks] f32 into fragment order:
+//   [cb = cout/64][chunk][tap][ks2][mt][lane][16 B];  element e of lane l:
+//   co = 64cb + 32mt + (l&31); ci = chunk*CPC + ks2*(CPC/2) + (l>>5)*EPL + e.
+void pack_conv_weights(const float* w, int cout, int cin, int ks, int esz, std::vector<uint8_t>& out) {
+  const int cpc = CHUNK_BYTES / esz, epl = 16 / esz, taps = ks * ks;
+  const int ncb = cout / 64, nch = cin / cpc;
+  out.assign((size_t)ncb * nch * taps * SLAB_TAP, 0);
+  size_t o = 0;
+  for (int cb = 0; cb < ncb; ++cb)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int tap = 0; tap < taps; ++tap)
+        for (int k2 = 0; k2 < 2; ++k2)
+          for (int mt = 0; mt < 2; ++mt)
+            for (int l = 0; l < 64; ++l)
+              for (int e = 0; e < epl; ++e) {
+                const int co = cb * 64 + mt * 32 + (l & 31);
+                const int ci = ch * cpc + k2 * (cpc / 2) + (l >> 5) * epl + e;
+                const float v = w[((size_t)co * cin + ci) * taps + tap];
+                if (esz == 4) { memcpy(&out[o], &v, 4); o += 4; }
+                else { const uint16_t hb = host_bf16(v); memcpy(&out[o], &hb, 2); o += 2; }
+              }
+}
+
+// Stem weights [64][3][7][7].  bf16: [kh][t][mt][lane][8], slot i = 16t + 8h + j,
+// value W[co][c][kh][kw] for i-1 = 3kw + c in [0,21), else 0.
+// f32: [kh][s][mt][lane], slot i = 2s + h.
+void pack_stem_weights(const float* w, int esz, std::vector<uint8_t>& out) {
+  auto slot = [&](int co, int kh, int i) -> float {
+    if (i < 1 || i > 21) return 0.f;
+    const int kw = (i - 1) / 3, c = (i - 1) % 3;
+    return w[((size_t)(co * 3 + c) * 7 + kh) * 7 + kw];
+  };
+  if (esz == 2) {
+    out.assign((size_t)7 * 2 * 2 * FRAG_BYTES, 0);
+    size_t o = 0;
+    for (int kh = 0; kh < 7; ++kh)
+      for (int t = 0; t < 2; ++t)
+        for (int mt = 0; mt < 2; ++mt)
+          for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+              const uint16_t hb = host_bf16(slot(mt * 32 + (l & 31), kh, 16 * t + 8 * (l >> 5) + j));
+              memcpy(&out[o], &hb, 2); o += 2;
+            }
+  } else {
+    out.assign((size_t)7 * 11 * 2 * 256, 0);
+    size_t o = 0;
+    for (int kh = 0; kh < 7; ++kh)
+      for (int s = 0; s < 11; ++s)
+        for (int mt = 0; mt < 2; ++mt)
+          for (int l = 0; l < 64; ++l) {
+            const float v = slot(mt * 32 + (l & 31), kh, 2 * s + (l >> 5));
+            memcpy(&out[o], &v, 4); o += 4;
+          }
+  }
+}
+
+template <typename T, int KS, int STRIDE, bool HALO>
+int launch_conv(const ConvParams& p, hipStream_t st) {
+  const int npx_lds = HALO ? p.IMGS * (p.TH + 2) * (p.TW + 2) : 256;
+  const size_t lds = (size_t)KS * KS * SLAB_TAP + (size_t)npx_lds * PIX_PITCH;
+  const int blocks_per_img = p.tiles_y * p.tiles_x;
+  const int groups = ((p.B + p.IMGS - 1) / p.IMGS) * blocks_per_img;
+  const int grid = groups * (p.Cout / 64);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, HALO>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, HALO>), dim3(grid), dim3(256), lds, st, p);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+template <typename T>
+int run_conv(const ConvLayer& L, const void* in, const void* res, void* out, int B, int Hi, int Wi,
+             bool relu, hipStream_t st, int* Ho_out, int* Wo_out) {
+  ConvParams p;
+  p.in = in; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = out;
+  p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = L.cin; p.Cout = L.cout;
+  const int pad = L.ks / 2;
+  p.Ho = (Hi + 2 * pad - L.ks) / L.stride + 1;
+  p.Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
+  if (p.Ho > 8 || p.Wo > 8) { p.TH = 16; p.TW = 16; p.IMGS = 1; }
+  else { p.TH = 8; p.TW = 8; p.IMGS = 4; }
+  p.tiles_y = (p.Ho + p.TH - 1) / p.TH; p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
+  p.relu = relu ? 1 : 0;
+  *Ho_out = p.Ho; *Wo_out = p.Wo;
+  DH_REQUIRE((int64_t)B * Hi * Wi * L.cin * (int64_t)sizeof(T) < ((int64_t)1 << 32),
+             "conv %s: input larger than 4 GiB, reduce the batch", L.name.c_str());
+  if (L.ks == 3 && L.stride == 1) return launch_conv<T, 3, 1, true>(p, st);
+  if (L.ks == 3 && L.stride == 2) return launch_conv<T, 3, 2, false>(p, st);
+  if (L.ks == 1 && L.stride == 2) return launch_conv<T, 1, 2, false>(p, st);
+  dh::set_error("conv %s: unsupported shape", L.name.c_str());
+  return DH_EINVAL;
+}
+
+template <typename T>
+int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t slide_w,
+                 const int32_t* yx, int64_t n64, int P, float* logits, hipStream_t st) {
+  const int B = (int)n64;
+  const int esz = (int)sizeof(T);
+  const int H1 = (P + 6 - 7) / 2 + 1;       // stem out
+  const int H2 = (H1 + 2 - 3) / 2 + 1;      // pool out
+  const size_t stem_bytes = (size_t)B * H1 * H1 * 64 * esz;
+  const size_t act_bytes = (size_t)B * H2 * H2 * 64 * esz;  // largest post-pool activation
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t need = al(stem_bytes) + 3 * al(act_bytes);
+  if (need > net->ws_bytes) {
+    if (net->ws) DH_HIP(hipFree(net->ws));
+    net->ws = nullptr; net->ws_bytes = 0;
+    DH_HIP(hipMalloc(&net->ws, need));
+    net->ws_bytes = need;
+  }
+  char* base = static_cast<char*>(net->ws);
+  void* S = base;
+  void* bufA = base + al(stem_bytes);
+  void* bufB = base + al(stem_bytes) + al(act_bytes);
+  void* bufC = base + al(stem_bytes) + 2 * al(act_bytes);
+
+  // stem
+  {
+    StemParams sp;
+    sp.x_nchw = x; sp.slide = slide; sp.yx = yx; sp.row_bytes = slide_w * 3;
+    sp.w = net->convs[0].w_dev; sp.scale = net->convs[0].scale_dev; sp.shift = net->convs[0].shift_dev;
+    sp.out = S; sp.B = B; sp.P = P; sp.Ho = H1; sp.Wo = H1;
+    sp.tiles_y = (H1 + STEM_TH - 1) / STEM_TH; sp.tiles_x = (H1 + STEM_TW - 1) / STEM_TW;
+    const size_t wb = esz == 2 ? (size_t)7 * 2 * 2 * FRAG_BYTES : (size_t)7 * 11 * 2 * 256;
+    const size_t lds = wb + (size_t)STEM_ROWS * STEM_ROWE * esz;
+    const int grid = B * sp.tiles_y * sp.tiles_x;
+    if (slide) {
+      static bool a = false;
+      if (!a) { DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); a = true; }
+      hipLaunchKernelGGL((stem_kernel<T, true>), dim3(grid), dim3(256), lds, st, sp);
+    } else {
+      static bool a = false;
+      if (!a) { DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); a = true; }
+      hipLaunchKernelGGL((stem_kernel<T, false>), dim3(grid), dim3(256), lds, st, sp);
+    }
+    DH_LAUNCH_CHECK();
+  }
+  // maxpool
+  {
+    const int64_t total = (int64_t)B * H2 * H2 * (64 / (16 / esz));
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL((maxpool_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(S),
+                       static_cast<T*>(bufA), B, H1, H1, 64, H2, H2);
+    DH_LAUNCH_CHECK();
+  }
+  // residual stages: X lives in bufA; T in bufB; downsample in bufC
+  int H = H2, W = H2;
+  size_t ci = 1;
+  for (int s = 0; s < 4; ++s) {
+    for (int blk = 0; blk < 2; ++blk) {
+      const bool has_ds = (blk == 0 && s > 0);
+      const ConvLayer& c1 = net->convs[ci];
+      const ConvLayer& c2 = net->convs[ci + 1];
+      int Ho, Wo, h2, w2;
+      int rc = run_conv<T>(c1, bufA, nullptr, bufB, B, H, W, true, st, &Ho, &Wo);
+      if (rc) return rc;
+      const void* resid = bufA;
+      if (has_ds) {
+        rc = run_conv<T>(net->convs[ci + 2], bufA, nullptr, bufC, B, H, W, false, st, &h2, &w2);
+        if (rc) return rc;
+        resid = bufC;
+      }
+      rc = run_conv<T>(c2, bufB, resid, bufA, B, Ho, Wo, true, st, &h2, &w2);
+      if (rc) return rc;
+      H = Ho; W = Wo;
+      ci += has_ds ? 3 : 2;
+    }
+  }
+  hipLaunchKernelGGL((avgpool_fc_kernel<T>), dim3(B), dim3(256), 0, st, static_cast<const T*>(bufA), H * W,
+                     512, net->fc_w_dev, net->fc_b_dev, net->n_classes, logits);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+template <typename V>
+int upload(const std::vector<V>& v, void** dev) {
+  if (*dev) { DH_HIP(hipFree(*dev)); *dev = nullptr; }
+  DH_HIP(hipMalloc(dev, v.size() * sizeof(V)));
+  DH_HIP(hipMemcpy(*dev, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice));
+  return DH_OK;
+}
+
+}  // namespace
+
+extern "C" int dh_resnet18_create(dh_resnet18** out, int32_t n_classes, int32_t dtype) {
+  DH_REQUIRE(out != nullptr, "resnet18 create: null output");
+  DH_REQUIRE(n_classes > 0 && n_classes <= 1024, "resnet18 create: n_classes=%d", n_classes);
+  DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "resnet18 create: bad dtype %d", dtype);
+  auto* net = new dh_resnet18();
+  net->n_classes = n_classes;
+  net->dtype = dtype;
+  build_topology(net);
+  *out = net;
+  return DH_OK;
+}
+
+extern "C" void dh_resnet18_destroy(dh_resnet18* net) {
+  if (!net) return;
+  for (auto& c : net->convs) {
+    if (c.w_dev) (void)hipFree(c.w_dev);
+    if (c.scale_dev) (void)hipFree(c.scale_dev);
+    if (c.shift_dev) (void)hipFree(c.shift_dev);
+  }
+  if (net->fc_w_dev) (void)hipFree(net->fc_w_dev);
+  if (net->fc_b_dev) (void)hipFree(net->fc_b_dev);
+  if (net->ws) (void)hipFree(net->ws);
+  delete net;
+}
+
+extern "C" int dh_resnet18_set_param(dh_resnet18* net, const char* name, const float* data,
+                                     int64_t n_elem) {
+  DH_REQUIRE(net && name && data, "resnet18 set_param: null argument");
+  const int64_t want = expected_elems(net, name);
+  DH_REQUIRE(want >= 0, "resnet18 set_param: unknown parameter '%s'", name);
+  DH_REQUIRE(want == n_elem, "resnet18 set_param: '%s' has %lld elements, expected %lld", name,
+             (long long)n_elem, (long long)want);
+  net->params[name].assign(data, data + n_elem);
+  net->finalized = false;
+  return DH_OK;
+}
+
+extern "C" int dh_resnet18_finalize(dh_resnet18* net, void* stream) {
+  DH_REQUIRE(net != nullptr, "resnet18 finalize: null handle");
+  (void)stream;
+  auto get = [&](const std::string& k) -> const std::vector<float>* {
+    auto it = net->params.find(k);
+    return it == net->params.end() ? nullptr : &it->second;
+  };
+  const int esz = net->esz();
+  for (size_t i = 0; i < net->convs.size(); ++i) {
+    ConvLayer& c = net->convs[i];
+    const auto* w = get(c.name + ".weight");
+    const auto *g = get(c.bn + ".weight"), *b = get(c.bn + ".bias"), *m = get(c.bn + ".running_mean"),
+               *v = get(c.bn + ".running_var");
+    DH_REQUIRE(w && g && b && m && v, "resnet18 finalize: parameters of '%s' / '%s' are not all set",
+               c.name.c_str(), c.bn.c_str());
+    std::vector<uint8_t> packed;
+    if (i == 0) pack_stem_weights(w->data(), esz, packed);
+    else pack_conv_weights(w->data(), c.cout, c.cin, c.ks, esz, packed);
+    int rc = upload(packed, &c.w_dev);
+    if (rc) return rc;
+    // eval-mode BN (eps = 1e-5, torch default): y = x*scale + shift
+    std::vector<float> sc(c.cout), sh(c.cout);
+    for (int k = 0; k < c.cout; ++k) {
+      const double s = (double)(*g)[k] / sqrt((double)(*v)[k] + 1e-5);
+      sc[k] = (float)s;
+      sh[k] = (float)((double)(*b)[k] - (double)(*m)[k] * s);
+    }
+    rc = upload(sc, reinterpret_cast<void**>(&c.scale_dev));
+    if (rc) return rc;
+    rc = upload(sh, reinterpret_cast<void**>(&c.shift_dev));
+    if (rc) return rc;
+  }
+  const auto *fw = get("fc.weight"), *fb = get("fc.bias");
+  DH_REQUIRE(fw && fb, "resnet18 finalize: fc.weight / fc.bias are not set");
+  int rc = upload(*fw, reinterpret_cast<void**>(&net->fc_w_dev));
+  if (rc) return rc;
+  rc = upload(*fb, reinterpret_cast<void**>(&net->fc_b_dev));
+  if (rc) return rc;
+  net->finalized = true;
+  return DH_OK;
+}
+
+static int check_forward_args(dh_resnet18* net, int64_t n, int32_t P, const void* logits) {
+  DH_REQUIRE(net && logits, "resnet18 forward: null argument");
+  DH_REQUIRE(net->finalized, "resnet18 forward: call dh_resnet18_finalize after setting parameters");
+  DH_REQUIRE(n >= 0 && n <= 4096, "resnet18 forward: batch %lld out of range [0, 4096]", (long long)n);
+  DH_REQUIRE(P >= 32 && P <= 1024, "resnet18 forward: patch %d out of range [32, 1024]", P);
+  return DH_OK;
+}
+
+extern "C" int dh_resnet18_forward(dh_resnet18* net, const float* x, int64_t n, int32_t P,
+                                   float* logits, void* stream) {
+  int rc = check_forward_args(net, n, P, logits);
+  if (rc) return rc;
+  DH_REQUIRE(x != nullptr, "resnet18 forward: null input");
+  if (n == 0) return DH_OK;
+  hipStream_t st = dh::as_stream(stream);
+  return net->dtype == DH_DTYPE_F32
+             ? forward_impl<float>(net, x, nullptr, 0, nullptr, n, P, logits, st)
+             : forward_impl<__bf16>(net, x, nullptr, 0, nullptr, n, P, logits, st);
+}
+
+extern "C" int dh_resnet18_forward_tiles(dh_resnet18* net, const uint8_t* slide, int64_t h, int64_t w,
+                                         const int32_t* yx, int64_t n, int32_t P, float* logits,
+                                         void* stream) {
+  int rc = check_forward_args(net, n, P, logits);
+  if (rc) return rc;
+  DH_REQUIRE(slide && yx, "resnet18 forward_tiles: null slide or origins");
+  DH_REQUIRE(h >= P && w >= P, "resnet18 forward_tiles: patch %d does not fit %lldx%lld", P,
+             (long long)h, (long long)w);
+  if (n == 0) return DH_OK;
+  hipStream_t st = dh::as_stream(stream);
+  return net->dtype == DH_DTYPE_F32
+             ? forward_impl<float>(net, nullptr, slide, w, yx, n, P, logits, st)
+             : forward_impl<__bf16>(net, nullptr, slide, w, yx, n, P, logits, st);
+}
+
+// ---------------------------------------------------------------------------
+// Test hooks (declared in include/deephisto_hip.h under "debug"): run one conv
+// layer on caller-provided NHWC data, and read back the stem activation of the
+// last forward.  They exist so the GPU parity tests can localise an error to a
+// kernel; the product path never calls them.
+// ---------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ void to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if constexpr (sizeof(T) == 2) out[i] = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(in)[i]);
+    else out[i] = in[i];
+  }
+}
+}  // namespace
+
+extern "C" int dh_debug_conv_bn_act(const void* in_dev, const float* w_host, const float* scale_host,
+                                    const float* shift_host, const void* res_dev, void* out_dev,
+                                    int32_t B, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                                    int32_t ks, int32_t stride, int32_t relu, int32_t dtype,
+                                    void* stream) {
+  DH_REQUIRE(in_dev && w_host && scale_host && shift_host && out_dev, "debug conv: null pointer");
+  DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "debug conv: bad dtype");
+  const int esz = dtype == DH_DTYPE_F32 ? 4 : 2;
+  DH_REQUIRE(cout % 64 == 0 && cin % (CHUNK_BYTES / esz) == 0, "debug conv: channel counts");
+  ConvLayer L{"debug", "debug", cin, cout, ks, stride};
+  std::vector<uint8_t> packed;
+  pack_conv_weights(w_host, cout, cin, ks, esz, packed);
+  int rc = upload(packed, &L.w_dev);
+  if (rc) return rc;
+  std::vector<float> sc(scale_host, scale_host + cout), sh(shift_host, shift_host + cout);
+  rc = upload(sc, reinterpret_cast<void**>(&L.scale_dev));
+  if (!rc) rc = upload(sh, reinterpret_cast<void**>(&L.shift_dev));
+  int ho, wo;
+  hipStream_t st = dh::as_stream(stream);
+  if (!rc)
+    rc = dtype == DH_DTYPE_F32 ? run_conv<float>(L, in_dev, res_dev, out_dev, B, H, W, relu != 0, st, &ho, &wo)
+                               : run_conv<__bf16>(L, in_dev, res_dev, out_dev, B, H, W, relu != 0, st, &ho, &wo);
+  hipError_t e = hipStreamSynchronize(st);
+  if (L.w_dev) (void)hipFree(L.w_dev);
+  if (L.scale_dev) (void)hipFree(L.scale_dev);
+  if (L.shift_dev) (void)hipFree(L.shift_dev);
+  if (!rc && e != hipSuccess) { dh::set_error("debug conv: %s", hipGetErrorString(e)); rc = DH_EHIP; }
+  return rc;
+}
+
+extern "C" int dh_debug_stem_out(dh_resnet18* net, int64_t n, int32_t P, float* out_dev, void* stream) {
+  DH_REQUIRE(net && out_dev && net->ws, "debug stem out: no forward has run");
+  const int H1 = (P + 6 - 7) / 2 + 1;
+  const int64_t elems = n * H1 * H1 * 64;
+  DH_REQUIRE((size_t)elems * net->esz() <= net->ws_bytes, "debug stem out: workspace smaller than request");
+  hipStream_t st = dh::as_stream(stream);
+  if (net->dtype == DH_DTYPE_F32)
+    hipLaunchKernelGGL((to_f32_kernel<float>), dim3(1024), dim3(256), 0, st, static_cast<const float*>(net->ws), out_dev, elems);
+  else
+    hipLaunchKernelGGL((to_f32_kernel<__bf16>), dim3(1024), dim3(256), 0, st, static_cast<const __bf16*>(net->ws), out_dev, elems);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}

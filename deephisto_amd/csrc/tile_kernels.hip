@@ -1,0 +1,434 @@
+// Tile-side kernels of the deephisto hot path for MI355X (gfx950, wave64):
+//   a1  dh_tile_grid            host integer restatement of the dense grid order
+//   --  dh_synth_slide          closed-form benchmark slide generated in HBM
+//   a2/a4/a5 dh_tile_gather     uint8 HWC slide -> [n,P,P,3] / [n,3,P,P] f32|bf16, exactly k/255
+//   a8  dh_accumulate_logits    ordered (bit-exact) canvas accumulation, dh_argmax_map
+// All of these are HBM-bound byte/integer work: no LDS, no MFMA; the design
+// rules are full-width coalesced rows (one wave = one tile row) and 16-byte stores.
+#include <stdarg.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "dh_common.h"
+
+namespace dh {
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+}  // namespace dh
+
+extern "C" int dh_abi_version(void) { return 1; }
+extern "C" const char* dh_last_error(void) { return dh::g_err.c_str(); }
+
+// ---------------------------------------------------------------------------
+// a1: tile grid (host).  Reference: patch_samplers/full_samplers.py:374-404.
+// ---------------------------------------------------------------------------
+static inline int64_t range_len(int64_t stop, int64_t step) {  // len(range(0, stop, step))
+  return stop <= 0 ? 0 : (stop + step - 1) / step;
+}
+
+extern "C" int dh_tile_grid_count(int64_t h, int64_t w, int32_t patch, int32_t stride,
+                                  int32_t batch, int64_t* n_unique, int64_t* n_padded) {
+  DH_REQUIRE(patch > 0 && stride > 0 && batch > 0, "tile grid: patch, stride, batch must be > 0");
+  DH_REQUIRE(h >= patch && w >= patch, "tile grid: slide %lldx%lld smaller than patch %d",
+             (long long)h, (long long)w, patch);
+  DH_REQUIRE(h <= INT32_MAX && w <= INT32_MAX, "tile grid: slide side exceeds int32");
+  const int64_t ny = range_len(h - patch, stride), nx = range_len(w - patch, stride);
+  const int64_t n = ny * nx + ny + nx + 1;
+  if (n_unique) *n_unique = n;
+  if (n_padded) *n_padded = (n + batch - 1) / batch * batch;
+  return DH_OK;
+}
+
+extern "C" int dh_tile_grid(int64_t h, int64_t w, int32_t patch, int32_t stride, int32_t batch,
+                            int32_t* out, int64_t capacity_pairs) {
+  int64_t n = 0, np = 0;
+  int rc = dh_tile_grid_count(h, w, patch, stride, batch, &n, &np);
+  if (rc) return rc;
+  DH_REQUIRE(out != nullptr, "tile grid: null output");
+  DH_REQUIRE(capacity_pairs >= np, "tile grid: capacity %lld < %lld padded origins",
+             (long long)capacity_pairs, (long long)np);
+  const int64_t ylim = h - patch, xlim = w - patch;
+  int32_t* p = out;
+  for (int64_t y = 0; y < ylim; y += stride)
+    for (int64_t x = 0; x < xlim; x += stride) { *p++ = (int32_t)y; *p++ = (int32_t)x; }
+  for (int64_t y = 0; y < ylim; y += stride) { *p++ = (int32_t)y; *p++ = (int32_t)xlim; }
+  for (int64_t x = 0; x < xlim; x += stride) { *p++ = (int32_t)ylim; *p++ = (int32_t)x; }
+  for (int64_t i = n - 1; i < np; ++i) {  // the corner, then its padding copies
+    *p++ = (int32_t)ylim; *p++ = (int32_t)xlim;
+  }
+  return DH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// synthetic slide: pix(y,x,c,seed) = (((y*K_Y)^(x*K_X)^(c*K_C)^(seed*K_S)) >> 7) & 0xFF
+// One thread = 16 consecutive bytes of the HWC image (one 16-B store).
+// ---------------------------------------------------------------------------
+#define DH_KY 73856093u
+#define DH_KX 19349663u
+#define DH_KC 83492791u
+#define DH_KS 2654435761u
+
+__global__ __launch_bounds__(256) void synth_slide_kernel(uint8_t* __restrict__ out, int64_t total,
+                                                          uint32_t row_bytes, uint32_t seed_term) {
+  const int64_t chunks = (total + 15) >> 4;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = t << 4;
+    uint32_t y = (uint32_t)(i0 / row_bytes);
+    uint32_t xb = (uint32_t)(i0 - (int64_t)y * row_bytes);
+    uint32_t x = xb / 3u, c = xb - 3u * x;
+    uint32_t wv[4] = {0, 0, 0, 0};
+    const int nb = (total - i0 >= 16) ? 16 : (int)(total - i0);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const uint32_t v = (((y * DH_KY) ^ (x * DH_KX) ^ (c * DH_KC) ^ seed_term) >> 7) & 0xFFu;
+      wv[b >> 2] |= v << (8 * (b & 3));
+      if (++c == 3u) { c = 0; ++x; }
+      if (++xb == row_bytes) { xb = 0; x = 0; c = 0; ++y; }
+    }
+    if (nb == 16) {
+      *reinterpret_cast<uint4*>(out + i0) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    } else {
+      for (int b = 0; b < nb; ++b) out[i0 + b] = (uint8_t)(wv[b >> 2] >> (8 * (b & 3)));
+    }
+  }
+}
+
+extern "C" int dh_synth_slide(uint8_t* slide, int64_t h, int64_t w, uint32_t seed, void* stream) {
+  DH_REQUIRE(slide && h > 0 && w > 0, "synth slide: bad arguments");
+  DH_REQUIRE(w * 3 <= (int64_t)UINT32_MAX, "synth slide: row too long");
+  DH_REQUIRE((reinterpret_cast<uintptr_t>(slide) & 15) == 0, "synth slide: base must be 16-B aligned");
+  const int64_t total = h * w * 3;
+  const int64_t chunks = (total + 15) >> 4;
+  const int grid = (int)std::min<int64_t>((chunks + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(synth_slide_kernel, dim3(grid), dim3(256), 0, dh::as_stream(stream), slide,
+                     total, (uint32_t)(w * 3), seed * DH_KS);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a2/a4/a5: gather.  k/255 in float32, correctly rounded, without a divide:
+//   q = k*r; e = fma(-q,255,k); q' = fma(e,r,q)   with r = RN(1/255).
+// (tests/test_div255.py checks all 256 inputs against IEEE division on the host;
+//  tests/test_gpu_tiles.py checks the kernel's outputs bit-for-bit.)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float div255(uint32_t k) {
+  const float r = 1.0f / 255.0f;
+  const float kf = (float)k;
+  const float q = kf * r;
+  const float e = __builtin_fmaf(-q, 255.0f, kf);
+  return __builtin_fmaf(e, r, q);
+}
+
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {  // RNE; inputs are finite
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+struct __attribute__((packed, aligned(1))) Px4 { uint32_t a, b, c; };   // 4 RGB pixels
+struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
+
+constexpr int GATHER_ROWS = 16;  // tile rows per 256-thread block (4 per wave)
+
+// NCHW: one wave = one tile row; lane j owns pixels 4j..4j+3 (12 contiguous bytes) and
+// writes one 16-B (f32) / 8-B (bf16) store into each of the three planes.
+template <bool BF16>
+__global__ __launch_bounds__(256) void gather_nchw_kernel(const uint8_t* __restrict__ slide,
+                                                          int64_t row_bytes,
+                                                          const int32_t* __restrict__ yx, int P,
+                                                          void* __restrict__ outv) {
+  const int t = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y0 = yx[2 * t], x0 = yx[2 * t + 1];
+  const int r0 = blockIdx.x * GATHER_ROWS + wave;
+  const int64_t plane = (int64_t)P * P;
+  for (int pj = lane * 4; pj < P; pj += 256) {
+#pragma unroll
+    for (int rr = 0; rr < GATHER_ROWS / 4; ++rr) {
+      const int r = r0 + rr * 4;
+      if (r < P) {
+        const uint8_t* src = slide + (int64_t)(y0 + r) * row_bytes + (int64_t)(x0 + pj) * 3;
+        const Px4 v = *reinterpret_cast<const Px4*>(src);
+        const uint32_t b[3] = {v.a, v.b, v.c};
+        float f[3][4];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) f[i % 3][i / 3] = div255((b[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+        const int64_t o = (int64_t)t * 3 * plane + (int64_t)r * P + pj;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if constexpr (BF16) {
+            uint2 w;
+            w.x = f32_to_bf16_bits(f[c][0]) | (f32_to_bf16_bits(f[c][1]) << 16);
+            w.y = f32_to_bf16_bits(f[c][2]) | (f32_to_bf16_bits(f[c][3]) << 16);
+            *reinterpret_cast<uint2*>(static_cast<uint16_t*>(outv) + o + c * plane) = w;
+          } else {
+            *reinterpret_cast<float4*>(static_cast<float*>(outv) + o + c * plane) =
+                make_float4(f[c][0], f[c][1], f[c][2], f[c][3]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// NHWC: the tile row is 3P contiguous bytes -> 3P contiguous outputs; lane j owns
+// bytes 4j..4j+3 of each 256-byte piece (4-B load, 16-B / 8-B store).
+template <bool BF16>
+__global__ __launch_bounds__(256) void gather_nhwc_kernel(const uint8_t* __restrict__ slide,
+                                                          int64_t row_bytes,
+                                                          const int32_t* __restrict__ yx, int P,
+                                                          void* __restrict__ outv) {
+  const int t = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y0 = yx[2 * t], x0 = yx[2 * t + 1];
+  const int r0 = blockIdx.x * GATHER_ROWS + wave;
+  const int rowlen = 3 * P;  // multiple of 4 (P % 4 == 0)
+  for (int bj = lane * 4; bj < rowlen; bj += 256) {
+#pragma unroll
+    for (int rr = 0; rr < GATHER_ROWS / 4; ++rr) {
+      const int r = r0 + rr * 4;
+      if (r < P) {
+        const uint8_t* src = slide + (int64_t)(y0 + r) * row_bytes + (int64_t)x0 * 3 + bj;
+        const uint32_t v = reinterpret_cast<const U32u*>(src)->v;
+        const float f0 = div255(v & 0xFFu), f1 = div255((v >> 8) & 0xFFu),
+                    f2 = div255((v >> 16) & 0xFFu), f3 = div255(v >> 24);
+        const int64_t o = ((int64_t)t * P + r) * rowlen + bj;
+        if constexpr (BF16) {
+          uint2 w;
+          w.x = f32_to_bf16_bits(f0) | (f32_to_bf16_bits(f1) << 16);
+          w.y = f32_to_bf16_bits(f2) | (f32_to_bf16_bits(f3) << 16);
+          *reinterpret_cast<uint2*>(static_cast<uint16_t*>(outv) + o) = w;
+        } else {
+          *reinterpret_cast<float4*>(static_cast<float*>(outv) + o) = make_float4(f0, f1, f2, f3);
+        }
+      }
+    }
+  }
+}
+
+// Any patch size (P % 4 != 0): one thread per output element.
+template <bool BF16, bool NCHW>
+__global__ __launch_bounds__(256) void gather_generic_kernel(const uint8_t* __restrict__ slide,
+                                                             int64_t row_bytes,
+                                                             const int32_t* __restrict__ yx, int P,
+                                                             void* __restrict__ outv) {
+  const int t = blockIdx.y;
+  const int y0 = yx[2 * t], x0 = yx[2 * t + 1];
+  const int64_t per_tile = (int64_t)P * P * 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_tile;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (3 * P));
+    const int rem = (int)(i - (int64_t)r * 3 * P);
+    const int px = rem / 3, c = rem - 3 * px;
+    const float f = div255(slide[(int64_t)(y0 + r) * row_bytes + (int64_t)(x0 + px) * 3 + c]);
+    const int64_t o = (int64_t)t * per_tile + (NCHW ? ((int64_t)c * P + r) * P + px : i);
+    if constexpr (BF16) static_cast<uint16_t*>(outv)[o] = (uint16_t)f32_to_bf16_bits(f);
+    else static_cast<float*>(outv)[o] = f;
+  }
+}
+
+extern "C" int dh_tile_gather(const uint8_t* slide, int64_t h, int64_t w, const int32_t* yx_dev,
+                              const int32_t* yx_host_check, int64_t n, int32_t P, int32_t layout,
+                              int32_t dtype, void* out, void* stream) {
+  DH_REQUIRE(slide && yx_dev && out, "tile gather: null pointer");
+  DH_REQUIRE(P > 0 && h >= P && w >= P, "tile gather: patch %d does not fit %lldx%lld", P,
+             (long long)h, (long long)w);
+  DH_REQUIRE(layout == DH_LAYOUT_NHWC || layout == DH_LAYOUT_NCHW, "tile gather: bad layout %d", layout);
+  DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "tile gather: bad dtype %d", dtype);
+  DH_REQUIRE(n >= 0 && n <= 65535, "tile gather: n=%lld out of range [0, 65535]", (long long)n);
+  if (n == 0) return DH_OK;
+  if (yx_host_check)
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t y = yx_host_check[2 * i], x = yx_host_check[2 * i + 1];
+      DH_REQUIRE(y >= 0 && x >= 0 && y + P <= h && x + P <= w,
+                 "tile gather: origin %lld = (%lld,%lld) outside slide", (long long)i, (long long)y,
+                 (long long)x);
+    }
+  const int esz = dtype == DH_DTYPE_F32 ? 4 : 2;
+  const bool fast = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  (void)esz;
+  hipStream_t st = dh::as_stream(stream);
+  const int64_t rb = w * 3;
+  if (fast) {
+    dim3 grid((P + GATHER_ROWS - 1) / GATHER_ROWS, (unsigned)n), block(256);
+    if (layout == DH_LAYOUT_NCHW) {
+      if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL(gather_nchw_kernel<false>, grid, block, 0, st, slide, rb, yx_dev, P, out);
+      else hipLaunchKernelGGL(gather_nchw_kernel<true>, grid, block, 0, st, slide, rb, yx_dev, P, out);
+    } else {
+      if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL(gather_nhwc_kernel<false>, grid, block, 0, st, slide, rb, yx_dev, P, out);
+      else hipLaunchKernelGGL(gather_nhwc_kernel<true>, grid, block, 0, st, slide, rb, yx_dev, P, out);
+    }
+  } else {
+    const int64_t per_tile = (int64_t)P * P * 3;
+    dim3 grid((unsigned)std::min<int64_t>((per_tile + 255) / 256, 1024), (unsigned)n), block(256);
+    if (layout == DH_LAYOUT_NCHW) {
+      if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL((gather_generic_kernel<false, true>), grid, block, 0, st, slide, rb, yx_dev, P, out);
+      else hipLaunchKernelGGL((gather_generic_kernel<true, true>), grid, block, 0, st, slide, rb, yx_dev, P, out);
+    } else {
+      if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL((gather_generic_kernel<false, false>), grid, block, 0, st, slide, rb, yx_dev, P, out);
+      else hipLaunchKernelGGL((gather_generic_kernel<true, false>), grid, block, 0, st, slide, rb, yx_dev, P, out);
+    }
+  }
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+__global__ void coords_kernel(const int32_t* __restrict__ yx, int64_t n2, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n2) out[i] = (float)yx[i];
+}
+
+extern "C" int dh_tile_coords_f32(const int32_t* yx_dev, int64_t n, float* out, void* stream) {
+  DH_REQUIRE(yx_dev && out && n >= 0, "tile coords: bad arguments");
+  if (n == 0) return DH_OK;
+  hipLaunchKernelGGL(coords_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0,
+                     dh::as_stream(stream), yx_dev, 2 * n, out);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a8: ordered accumulation.  The canvas is cut into bins of G x G cells
+// (G = max(1, P/d)); the host builds, per bin, the list of tiles that touch it,
+// in tile order.  One workgroup owns one bin, so every canvas cell has exactly
+// one writer that applies the covering tiles' logits sequentially in the
+// reference's order: float32 results are bit-identical to the NumPy `+=` loop,
+// with no atomics.  Traffic: canvas read+write once, logits/lists from L2.
+// ---------------------------------------------------------------------------
+struct BinGeom { int32_t G, bins_x, dh, dw, n_cls, P, d; };
+
+__global__ __launch_bounds__(256) void accumulate_bins_kernel(
+    const float* __restrict__ logits, const int32_t* __restrict__ yx,
+    const int32_t* __restrict__ bin_start, const int32_t* __restrict__ bin_tiles, BinGeom g,
+    float* __restrict__ canvas) {
+  __shared__ int32_t s_t[256], s_y0[256], s_y1[256], s_x0[256], s_x1[256];
+  const int bin = blockIdx.x;
+  const int beg = bin_start[bin], end = bin_start[bin + 1];
+  if (beg == end) return;  // uniform for the block
+  const int by = bin / g.bins_x, bx = bin - by * g.bins_x;
+  const int cells = g.G * g.G, items = cells * g.n_cls;
+  for (int it0 = 0; it0 < items; it0 += 256) {
+    const int it = it0 + threadIdx.x;
+    const int cell = it / g.n_cls, cls = it - cell * g.n_cls;
+    const int cy = by * g.G + cell / g.G, cx = bx * g.G + cell % g.G;
+    const bool live = it < items && cy < g.dh && cx < g.dw;
+    const int64_t addr = ((int64_t)cy * g.dw + cx) * g.n_cls + cls;
+    float acc = live ? canvas[addr] : 0.f;
+    for (int l0 = beg; l0 < end; l0 += 256) {
+      __syncthreads();
+      const int l = l0 + threadIdx.x;
+      if (l < end) {
+        const int t = bin_tiles[l];
+        const int y = yx[2 * t], x = yx[2 * t + 1];
+        s_t[threadIdx.x] = t;
+        s_y0[threadIdx.x] = y / g.d; s_y1[threadIdx.x] = (y + g.P) / g.d;
+        s_x0[threadIdx.x] = x / g.d; s_x1[threadIdx.x] = (x + g.P) / g.d;
+      }
+      __syncthreads();
+      const int m = min(256, end - l0);
+      if (live)
+        for (int k = 0; k < m; ++k)
+          if (cy >= s_y0[k] && cy < s_y1[k] && cx >= s_x0[k] && cx < s_x1[k])
+            acc = acc + logits[(int64_t)s_t[k] * g.n_cls + cls];
+    }
+    if (live) canvas[addr] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ canvas, int64_t n_cells,
+                                                     int n_cls, int64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float* p = canvas + i * n_cls;
+    float best = p[0];
+    int bi = 0;
+    for (int c = 1; c < n_cls; ++c) {  // NumPy argmax: first maximum; a NaN wins once
+      const float v = p[c];
+      if (v > best || (v != v && best == best)) { best = v; bi = c; }
+    }
+    out[i] = bi;
+  }
+}
+
+extern "C" int dh_argmax_map(const float* canvas, int64_t n_cells, int32_t n_cls, int64_t* map,
+                             void* stream) {
+  DH_REQUIRE(canvas && map && n_cells >= 0 && n_cls > 0, "argmax map: bad arguments");
+  if (n_cells == 0) return DH_OK;
+  const int grid = (int)std::min<int64_t>((n_cells + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(argmax_kernel, dim3(grid), dim3(256), 0, dh::as_stream(stream), canvas, n_cells,
+                     n_cls, map);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_accumulate_logits(const float* logits, const int32_t* yx_host, int64_t n,
+                                    int32_t P, int32_t d, int32_t n_cls, int64_t h, int64_t w,
+                                    float* canvas, int64_t* map, void* stream) {
+  DH_REQUIRE(logits && yx_host && canvas, "accumulate: null pointer");
+  DH_REQUIRE(P > 0 && d > 0 && n_cls > 0 && h > 0 && w > 0 && n >= 0, "accumulate: bad sizes");
+  DH_REQUIRE(n <= INT32_MAX / 8, "accumulate: too many tiles");
+  const int64_t dh_ = h / d, dw_ = w / d;
+  hipStream_t st = dh::as_stream(stream);
+  if (dh_ == 0 || dw_ == 0) return DH_OK;
+  DH_REQUIRE(dh_ * dw_ <= (int64_t)INT32_MAX, "accumulate: canvas too large");
+  if (n > 0) {
+    const int G = std::max(1, std::min(P / d, 64));
+    const int64_t bins_y = (dh_ + G - 1) / G, bins_x = (dw_ + G - 1) / G;
+    const int64_t nbins = bins_y * bins_x;
+    DH_REQUIRE(nbins < INT32_MAX, "accumulate: too many bins");
+    std::vector<int32_t> start(nbins + 1, 0);
+    auto span = [&](int64_t i, int64_t& cy0, int64_t& cy1, int64_t& cx0, int64_t& cx1) {
+      const int64_t y = yx_host[2 * i], x = yx_host[2 * i + 1];
+      cy0 = std::max<int64_t>(y / d, 0); cy1 = std::min<int64_t>((y + P) / d, dh_);
+      cx0 = std::max<int64_t>(x / d, 0); cx1 = std::min<int64_t>((x + P) / d, dw_);
+      return y >= 0 && x >= 0 && cy1 > cy0 && cx1 > cx0;
+    };
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t a, b, c, e;
+      DH_REQUIRE(yx_host[2 * i] >= 0 && yx_host[2 * i + 1] >= 0, "accumulate: negative origin");
+      if (!span(i, a, b, c, e)) continue;
+      for (int64_t by = a / G; by <= (b - 1) / G; ++by)
+        for (int64_t bx = c / G; bx <= (e - 1) / G; ++bx) { ++start[by * bins_x + bx + 1]; ++total; }
+    }
+    DH_REQUIRE(total < INT32_MAX, "accumulate: incidence list too long");
+    for (int64_t b = 0; b < nbins; ++b) start[b + 1] += start[b];
+    std::vector<int32_t> fill(start.begin(), start.end() - 1), tiles((size_t)std::max<int64_t>(total, 1));
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t a, b, c, e;
+      if (!span(i, a, b, c, e)) continue;
+      for (int64_t by = a / G; by <= (b - 1) / G; ++by)
+        for (int64_t bx = c / G; bx <= (e - 1) / G; ++bx) tiles[fill[by * bins_x + bx]++] = (int32_t)i;
+    }
+    if (total > 0) {
+      int32_t *d_start = nullptr, *d_tiles = nullptr, *d_yx = nullptr;
+      const size_t sb = (size_t)(nbins + 1) * 4, tb = (size_t)total * 4, yb = (size_t)n * 8;
+      DH_HIP(hipMallocAsync((void**)&d_start, sb, st));
+      DH_HIP(hipMallocAsync((void**)&d_tiles, tb, st));
+      DH_HIP(hipMallocAsync((void**)&d_yx, yb, st));
+      DH_HIP(hipMemcpyAsync(d_start, start.data(), sb, hipMemcpyHostToDevice, st));
+      DH_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tb, hipMemcpyHostToDevice, st));
+      DH_HIP(hipMemcpyAsync(d_yx, yx_host, yb, hipMemcpyHostToDevice, st));
+      BinGeom g{G, (int32_t)bins_x, (int32_t)dh_, (int32_t)dw_, n_cls, P, d};
+      hipLaunchKernelGGL(accumulate_bins_kernel, dim3((unsigned)nbins), dim3(256), 0, st, logits, d_yx,
+                         d_start, d_tiles, g, canvas);
+      DH_LAUNCH_CHECK();
+      DH_HIP(hipFreeAsync(d_start, st));
+      DH_HIP(hipFreeAsync(d_tiles, st));
+      DH_HIP(hipFreeAsync(d_yx, st));
+      // the host vectors above feed async copies: keep them alive until the stream drains
+      DH_HIP(hipStreamSynchronize(st));
+    }
+  }
+  if (map) return dh_argmax_map(canvas, dh_ * dw_, n_cls, map, stream);
+  return DH_OK;
+}

@@ -1,0 +1,171 @@
+"""Whole-slide patched prediction -- drop-in for examples/predict_full_patched.py.
+
+Keeps `ImagePredictorPatched(psim_path, patch_sampler, batch_predictor, anno, layer,
+downscale).process()`, `batch_predictor(patches, model, device)` and
+`load_model(weights_path, device)` (predict_full_patched.py:22-78, 116-126), and adds
+`predict_full_patched(...)`, the device-resident fast path used by bench.py:
+tile ranges are sharded over the ranks of a torch.distributed job (RCCL over
+xGMI), every rank runs fused gather+ResNet-18 on its range, per-tile logits are
+all-gathered, and the ordered accumulation + argmax run once.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Callable
+
+import numpy as np
+import torch
+
+from .. import tiles
+from .._lib import DH_LAYOUT_NCHW
+from ..models.patch_cls_simple.model import ResNet18HIP, get_model
+from ..patch_samplers.full_samplers import DevicePatch, FullImageDenseSampler
+from ..psimage_compat import Patch, open_slide
+
+
+def _n_classes(anno) -> int:
+    if hasattr(anno, "anno_classes"):  # AnnoDescription (predict_full_patched.py:43)
+        return len(anno.anno_classes)
+    return int(anno)
+
+
+class ImagePredictorPatched:
+    def __init__(
+        self,
+        psim_path,
+        patch_sampler,
+        batch_predictor: Callable[[list[Patch]], "np.ndarray"],
+        anno,
+        layer: int,
+        downscale: int = 4,
+        device="cuda",
+    ):
+        self.patch_sampler = patch_sampler
+        self.batch_predictor = batch_predictor
+        self.anno = anno
+        self.layer = layer
+        self.downscale = downscale
+        self.device = torch.device(device)
+        if isinstance(psim_path, (tuple, list)):  # (h, w) given directly
+            self.h, self.w = int(psim_path[0]), int(psim_path[1])
+        elif isinstance(psim_path, torch.Tensor):
+            self.h, self.w = int(psim_path.shape[0]), int(psim_path.shape[1])
+        else:
+            with open_slide(psim_path) as psim:
+                self.h, self.w = psim.layer_size(self.layer)
+
+    def process(self) -> np.ndarray:
+        """int64[h//d, w//d] class map.  Iterates the sampler and the caller's
+        batch_predictor like the reference (predict_full_patched.py:47-48); the per-patch
+        `prediction[...] += logits` loop and the argmax (:49-62) run on the GPU, in the
+        same order (padding duplicates included), once all batches are in."""
+        n = _n_classes(self.anno)
+        runs: list[tuple[int, list, list]] = []  # (patch_size, origins, logits) per run of equal size
+        for patches, _progress in self.patch_sampler:
+            preds = self.batch_predictor(patches)
+            if isinstance(preds, torch.Tensor):
+                preds = preds.detach().to(torch.float32)
+            else:
+                preds = torch.from_numpy(np.asarray(preds, dtype=np.float32))
+            if preds.shape[0] != len(patches) or preds.shape[1] != n:
+                raise ValueError(f"batch_predictor returned {tuple(preds.shape)} for {len(patches)} patches, {n} classes")
+            for i, p in enumerate(patches):
+                if not runs or runs[-1][0] != p.patch_size:
+                    runs.append((p.patch_size, [], []))
+                runs[-1][1].append((p.pos_y, p.pos_x))
+                runs[-1][2].append(preds[i:i + 1])
+        canvas, cmap = None, None
+        for ps, origins, logit_rows in runs:
+            logits = torch.cat(logit_rows).to(self.device).contiguous()
+            canvas, cmap = tiles.accumulate_logits(logits, np.asarray(origins, dtype=np.int32), ps,
+                                                   self.downscale, self.h, self.w, canvas=canvas)
+        if cmap is None:
+            return np.zeros((self.h // self.downscale, self.w // self.downscale), dtype=np.int64)
+        return cmap.cpu().numpy()
+
+
+def batch_predictor(patches: list[Patch], model, device) -> np.ndarray:
+    """float32[B, n_cls] raw logits for a list of patches (predict_full_patched.py:66-78).
+
+    Patches cut by this package's samplers are gathered from the HBM-resident slide
+    inside the stem kernel (no float copy of the pixels exists anywhere); foreign
+    patches carrying host arrays are uploaded as uint8 and gathered the same way."""
+    device = torch.device(device)
+    ps = patches[0].patch_size
+    origins = np.array([(p.pos_y, p.pos_x) for p in patches], dtype=np.int32)
+    if all(isinstance(p, DevicePatch) and p._sampler is patches[0]._sampler for p in patches):
+        slide = patches[0]._sampler.data_device
+    else:  # stack foreign host patches into a strip "slide" of B tiles
+        slide = torch.from_numpy(np.concatenate([np.asarray(p.data, dtype=np.uint8) for p in patches], axis=0)).to(device)
+        origins = np.array([(i * ps, 0) for i in range(len(patches))], dtype=np.int32)
+    o_dev = torch.from_numpy(origins).to(slide.device)
+    if isinstance(model, ResNet18HIP):
+        out = model.forward_tiles(slide, o_dev, ps)
+    else:  # any other nn.Module: build the NCHW float input with the gather kernel
+        with torch.no_grad():
+            out = model(tiles.gather_tiles(slide, o_dev, ps, DH_LAYOUT_NCHW, torch.float32))
+    return out.detach().cpu().numpy()
+
+
+def load_model(weights_path, device, compute_dtype: str = "f32") -> torch.nn.Module:
+    """predict_full_patched.py:116-126: 5-class model, state_dict loaded weights_only."""
+    model = get_model(n_classes=5, compute_dtype=compute_dtype).to(device)
+    model.load_state_dict(torch.load(weights_path, weights_only=True, map_location=device))
+    model.to(device).eval()
+    return model
+
+
+def shard_range(n_items: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous [lo, hi) share of `n_items` for `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_classes: int,
+                         downscale: int = 16, micro_batch: int | None = None, group=None,
+                         return_logits: bool = False):
+    """Device-resident whole-slide prediction (rows a1-a8 end to end).
+
+    Single process: every tile (padding duplicates included) goes through the fused
+    gather+ResNet-18 kernels in micro-batches, logits stay in HBM, one ordered
+    accumulate + argmax.  Under torch.distributed (one process per GPU, backend
+    "nccl" = RCCL): rank r takes the contiguous range shard_range(n_unique, world, r)
+    of the reference-ordered origin list, logits are exchanged with ONE all-gather
+    (n_unique x n_cls floats in total), and every rank finishes the map; the corner
+    tile's padding duplicates are reconstructed from the gathered logits so the
+    canvas equals the single-GPU / reference result.
+    Returns int64[h//d, w//d] on the device (and the float32[n_padded, n_cls] logits).
+    """
+    import torch.distributed as dist
+
+    slide = sampler.data_device
+    dev = slide.device
+    P = sampler.patch_size
+    origins = sampler.origins                      # padded, reference order
+    n_unique, n_padded = sampler.n_tiles, len(origins)
+    mb = micro_batch or sampler.batch_size
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    lo, hi = shard_range(n_unique, world, rank)
+    o_dev = torch.from_numpy(origins[lo:hi]).to(dev)
+    per_rank = -(-n_unique // world)
+    local = torch.zeros((per_rank, n_classes), dtype=torch.float32, device=dev)
+    for s in range(0, hi - lo, mb):
+        e = min(s + mb, hi - lo)
+        local[s:e] = model.forward_tiles(slide, o_dev[s:e].contiguous(), P)
+    if distributed:
+        gathered = torch.empty((world * per_rank, n_classes), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(gathered, local, group=group)
+        parts = []
+        for r in range(world):
+            rl, rh = shard_range(n_unique, world, r)
+            parts.append(gathered[r * per_rank:r * per_rank + (rh - rl)])
+        logits_unique = torch.cat(parts)
+    else:
+        logits_unique = local[:n_unique]
+    pad = n_padded - n_unique
+    logits = torch.cat([logits_unique, logits_unique[-1:].expand(pad, -1)]) if pad else logits_unique
+    _, cmap = tiles.accumulate_logits(logits.contiguous(), origins, P, downscale, sampler.h, sampler.w)
+    return (cmap, logits) if return_logits else cmap

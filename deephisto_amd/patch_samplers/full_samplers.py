@@ -1,0 +1,166 @@
+"""Full-slide samplers -- drop-in for patch_samplers/full_samplers.py (dense path).
+
+`FullImageDenseSampler` keeps the reference's constructor, attributes and iterator
+protocol (full_samplers.py:302-452).  What changes is where the work happens:
+
+* the tile-origin list is produced by `dh_tile_grid` (bit-exact with
+  `_create_batched_coords`, full_samplers.py:374-404);
+* the slide layer is made resident in HBM once (uint8 HWC), and
+  `generator_torch()` / `generator_device()` cut, normalise (k/255) and lay out the
+  batches with the `dh_tile_gather` kernel instead of NumPy slicing + astype +
+  divide + torch.tensor (full_samplers.py:353-369, 441-443);
+* `generator()` still yields `list[Patch]` for callers that bring their own
+  `batch_predictor`; `Patch.data` is a lazy host view so nothing is copied unless a
+  caller actually reads the pixels on the CPU.
+
+Documented deviations from the reference:
+  `stride=None` means `stride = patch_size` (the reference crashes);
+  a slide smaller than the patch raises ValueError (the reference yields negative origins);
+  `mode` defaults to INMEMORY_SINGLEPROC (predict_full_patched.py:165-167 omits it);
+  tensors from `generator_torch()` are on the sampler's device, not on the CPU.
+"""
+from __future__ import annotations
+
+from enum import Enum
+from pathlib import Path
+from typing import Iterable, Iterator
+
+import numpy as np
+import torch
+
+from .. import tiles
+from .._lib import DH_LAYOUT_NCHW, DH_LAYOUT_NHWC
+from ..psimage_compat import Patch, open_slide
+
+
+class SamplerExecutionMode(Enum):  # full_samplers.py:16-18
+    INMEMORY_SINGLEPROC = 1
+    ONDISK_MULTIPROC = 2
+
+
+class DevicePatch(Patch):
+    """A `Patch` whose pixels live in the sampler's HBM-resident slide.
+
+    `.data` materialises the uint8[P, P, 3] host view on first access (the reference
+    hands out NumPy views of the in-RAM layer, full_samplers.py:361-365)."""
+
+    def __init__(self, layer, pos_x, pos_y, patch_size, sampler):
+        self.layer, self.pos_x, self.pos_y, self.patch_size = layer, pos_x, pos_y, patch_size
+        self._sampler = sampler
+
+    @property
+    def data(self):
+        a = self._sampler.data
+        return a[self.pos_y:self.pos_y + self.patch_size, self.pos_x:self.pos_x + self.patch_size, :]
+
+    def __repr__(self):
+        return f"DevicePatch(layer={self.layer}, pos_x={self.pos_x}, pos_y={self.pos_y}, patch_size={self.patch_size})"
+
+
+class FullImageDenseSampler:
+    def __init__(
+        self,
+        psimage_path,
+        layer: int,
+        patch_size: int,
+        batch_size: int,
+        mode: SamplerExecutionMode = SamplerExecutionMode.INMEMORY_SINGLEPROC,
+        stride: int = None,
+        device="cuda",
+    ):
+        self._psim_path = psimage_path
+        self.mode = mode
+        self.layer = layer
+        self.device = torch.device(device)
+        self._host = None
+        self._dev = None
+        if isinstance(psimage_path, torch.Tensor):  # already a uint8[h,w,3] tensor (host or HBM)
+            t = psimage_path
+            if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+                raise ValueError("slide tensor must be uint8[h, w, 3]")
+            self.h, self.w = int(t.shape[0]), int(t.shape[1])
+            if t.is_cuda:
+                self._dev, self.device = t.contiguous(), t.device
+            else:
+                self._host = t.contiguous().numpy()
+        else:
+            with open_slide(psimage_path) as psim:
+                psim._assert_layer(layer)
+                self.h, self.w = psim.layer_size(self.layer)
+                if self.mode == SamplerExecutionMode.INMEMORY_SINGLEPROC:
+                    self._host = np.ascontiguousarray(
+                        psim.get_region_from_layer(self.layer, (0, 0), (self.h, self.w)))
+        if mode == SamplerExecutionMode.ONDISK_MULTIPROC and self._host is None and self._dev is None:
+            raise NotImplementedError(
+                "ONDISK_MULTIPROC streaming from .psi files is not built yet (SURVEY section 8f row 3); "
+                "use INMEMORY_SINGLEPROC")
+        self.patch_size = int(patch_size)
+        self.batch_size = int(batch_size)
+        self.stride = int(stride) if stride is not None else int(patch_size)
+        if self.h < self.patch_size or self.w < self.patch_size:
+            raise ValueError(f"slide {self.h}x{self.w} is smaller than the patch {self.patch_size}")
+        self._origins, self.n_tiles = tiles.tile_grid(self.h, self.w, self.patch_size, self.stride,
+                                                      self.batch_size)
+        print(f"Image {self.h} x {self.w}")
+
+    # ---- slide residency ------------------------------------------------------------
+    @property
+    def data(self) -> np.ndarray:
+        """uint8[h, w, 3] host array of the layer (reference attribute, :319-320)."""
+        if self._host is None:
+            self._host = self._dev.cpu().numpy()
+        return self._host
+
+    @property
+    def data_device(self) -> torch.Tensor:
+        """uint8[h, w, 3] slide resident in HBM (uploaded once, on first use)."""
+        if self._dev is None:
+            self._dev = torch.from_numpy(self._host).to(self.device)
+        return self._dev
+
+    # ---- grid ------------------------------------------------------------------------
+    @property
+    def origins(self) -> np.ndarray:
+        """int32[n_batches*batch_size, 2] (y, x) origins incl. the corner padding (a1)."""
+        return self._origins
+
+    def _create_batched_coords(self):
+        """list[list[(y, x)]] exactly as the reference returns it (:374-404)."""
+        o = self._origins.reshape(-1, self.batch_size, 2)
+        return [[(int(y), int(x)) for y, x in b] for b in o]
+
+    def __len__(self):
+        return len(self._origins) // self.batch_size
+
+    # ---- iterator protocol -------------------------------------------------------------
+    def __iter__(self) -> Iterable[tuple[list[Patch], float]]:
+        return self.generator()
+
+    def generator(self) -> Iterable[tuple[list[Patch], float]]:
+        nb = len(self)
+        o = self._origins.reshape(nb, self.batch_size, 2)
+        for i in range(nb):
+            patches = [DevicePatch(self.layer, int(x), int(y), self.patch_size, self) for y, x in o[i]]
+            yield patches, i / nb
+
+    def generator_device(self, layout: int = DH_LAYOUT_NCHW, dtype=torch.float32
+                         ) -> Iterator[tuple[torch.Tensor, np.ndarray, float]]:
+        """(tiles on device in `layout`/`dtype`, int32[B,2] host origins, progress)."""
+        nb = len(self)
+        slide = self.data_device
+        o = self._origins.reshape(nb, self.batch_size, 2)
+        o_dev = torch.from_numpy(self._origins).to(slide.device).reshape(nb, self.batch_size, 2)
+        for i in range(nb):
+            t = tiles.gather_tiles(slide, o_dev[i], self.patch_size, layout, dtype, check_bounds=False)
+            yield t, o[i], i / nb
+
+    def generator_torch(self) -> Iterator[tuple[torch.Tensor, torch.Tensor, float]]:
+        """(features f32[B,P,P,3] in [0,1], coords f32[B,2] (y,x), progress) -- :437-452."""
+        nb = len(self)
+        slide = self.data_device
+        o_dev = torch.from_numpy(self._origins).to(slide.device).reshape(nb, self.batch_size, 2)
+        for i in range(nb):
+            oi = o_dev[i].contiguous()
+            features = tiles.gather_tiles(slide, oi, self.patch_size, DH_LAYOUT_NHWC, torch.float32,
+                                          check_bounds=False)
+            yield features, tiles.tile_coords(oi), i / nb

@@ -1,0 +1,116 @@
+"""Thin torch-tensor wrappers over the tile-side C ABI (include/deephisto_hip.h).
+
+torch is used only for device memory and streams; every computation below runs
+in libdeephisto_hip.so.  No CPU fallbacks: a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import (DH_DTYPE_BF16, DH_DTYPE_F32, DH_LAYOUT_NCHW, DH_LAYOUT_NHWC, check, lib)
+
+_TORCH_DTYPE = {DH_DTYPE_F32: torch.float32, DH_DTYPE_BF16: torch.bfloat16}
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise ValueError(f"{what} must live in GPU memory (got {t.device})")
+    if not t.is_contiguous():
+        raise ValueError(f"{what} must be contiguous")
+
+
+def dtype_code(dtype) -> int:
+    if dtype in (torch.float32, "f32", "float32", DH_DTYPE_F32):
+        return DH_DTYPE_F32
+    if dtype in (torch.bfloat16, "bf16", "bfloat16", DH_DTYPE_BF16):
+        return DH_DTYPE_BF16
+    raise ValueError(f"unsupported dtype {dtype!r}")
+
+
+def tile_grid(h: int, w: int, patch: int, stride: int, batch: int) -> tuple[np.ndarray, int]:
+    """(int32[n_padded, 2] (y, x) origins in the reference's order, n_unique).
+
+    Host-side integer work done by dh_tile_grid (full_samplers.py:374-404)."""
+    nu, npad = C.c_int64(), C.c_int64()
+    check(lib().dh_tile_grid_count(h, w, patch, stride, batch, C.byref(nu), C.byref(npad)), "dh_tile_grid_count")
+    out = np.empty((npad.value, 2), dtype=np.int32)
+    check(lib().dh_tile_grid(h, w, patch, stride, batch, out.ctypes.data_as(C.c_void_p), npad.value), "dh_tile_grid")
+    return out, nu.value
+
+
+def synth_slide(h: int, w: int, seed: int = 0, device="cuda") -> torch.Tensor:
+    """uint8[h, w, 3] closed-form synthetic slide generated directly in HBM."""
+    dev = torch.device(device)
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    check(lib().dh_synth_slide(out.data_ptr(), h, w, seed & 0xFFFFFFFF, _stream(dev)), "dh_synth_slide")
+    return out
+
+
+def gather_tiles(slide: torch.Tensor, origins, patch: int, layout: int = DH_LAYOUT_NCHW,
+                 dtype=torch.float32, check_bounds: bool = True) -> torch.Tensor:
+    """Gather `patch` x `patch` tiles at int32 (y, x) `origins` from a device-resident
+    uint8 HWC slide; returns [n,3,P,P] (NCHW) or [n,P,P,3] (NHWC) values k/255."""
+    _require_cuda(slide, "slide")
+    if slide.dtype != torch.uint8 or slide.dim() != 3 or slide.shape[2] != 3:
+        raise ValueError("slide must be uint8[h, w, 3]")
+    h, w = int(slide.shape[0]), int(slide.shape[1])
+    host = None
+    if isinstance(origins, torch.Tensor):
+        yx_dev = origins.to(device=slide.device, dtype=torch.int32).contiguous()
+        if check_bounds:
+            host = np.ascontiguousarray(origins.detach().cpu().numpy().astype(np.int32))
+    else:
+        host = np.ascontiguousarray(np.asarray(origins, dtype=np.int32).reshape(-1, 2))
+        yx_dev = torch.from_numpy(host).to(slide.device)
+    n = int(yx_dev.shape[0])
+    code = dtype_code(dtype)
+    shape = (n, 3, patch, patch) if layout == DH_LAYOUT_NCHW else (n, patch, patch, 3)
+    out = torch.empty(shape, dtype=_TORCH_DTYPE[code], device=slide.device)
+    check(lib().dh_tile_gather(slide.data_ptr(), h, w, yx_dev.data_ptr(),
+                               host.ctypes.data_as(C.c_void_p) if (check_bounds and host is not None) else None,
+                               n, patch, layout, code, out.data_ptr(), _stream(slide.device)), "dh_tile_gather")
+    return out
+
+
+def tile_coords(origins_dev: torch.Tensor) -> torch.Tensor:
+    """float32[n, 2] (pos_y, pos_x) from int32 device origins (full_samplers.py:444-451)."""
+    _require_cuda(origins_dev, "origins")
+    n = int(origins_dev.shape[0])
+    out = torch.empty((n, 2), dtype=torch.float32, device=origins_dev.device)
+    check(lib().dh_tile_coords_f32(origins_dev.data_ptr(), n, out.data_ptr(), _stream(origins_dev.device)),
+          "dh_tile_coords_f32")
+    return out
+
+
+def accumulate_logits(logits: torch.Tensor, origins_host: np.ndarray, patch: int, downscale: int,
+                      h: int, w: int, canvas: torch.Tensor | None = None,
+                      want_map: bool = True) -> tuple[torch.Tensor, torch.Tensor | None]:
+    """Ordered accumulation of per-tile logits into the downscaled canvas and argmax
+    (examples/predict_full_patched.py:41-62).  Returns (canvas f32[dh,dw,n], map int64[dh,dw])."""
+    _require_cuda(logits, "logits")
+    if logits.dtype != torch.float32 or logits.dim() != 2:
+        raise ValueError("logits must be float32[n, n_cls]")
+    yx = np.ascontiguousarray(np.asarray(origins_host, dtype=np.int32).reshape(-1, 2))
+    n, n_cls = int(logits.shape[0]), int(logits.shape[1])
+    if yx.shape[0] != n:
+        raise ValueError(f"{n} logit rows but {yx.shape[0]} origins")
+    dh_, dw_ = h // downscale, w // downscale
+    if canvas is None:
+        canvas = torch.zeros((dh_, dw_, n_cls), dtype=torch.float32, device=logits.device)
+    else:
+        _require_cuda(canvas, "canvas")
+        if tuple(canvas.shape) != (dh_, dw_, n_cls) or canvas.dtype != torch.float32:
+            raise ValueError("canvas must be float32[h//d, w//d, n_cls]")
+    cmap = torch.empty((dh_, dw_), dtype=torch.int64, device=logits.device) if want_map else None
+    check(lib().dh_accumulate_logits(logits.data_ptr(), yx.ctypes.data_as(C.c_void_p), n, patch, downscale,
+                                     n_cls, h, w, canvas.data_ptr(),
+                                     cmap.data_ptr() if cmap is not None else None,
+                                     _stream(logits.device)), "dh_accumulate_logits")
+    return canvas, cmap

@@ -1,0 +1,139 @@
+/* deephisto_hip.h -- C ABI of libdeephisto_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the deephisto whole-slide patch hot path
+ * (patch_samplers.full_samplers.FullImageDenseSampler ->
+ *  examples.predict_full_patched.{batch_predictor, ImagePredictorPatched} ->
+ *  models.patch_cls_simple.model.get_model).  The reference is pure Python and
+ * has no FFI of its own; each entry point below names
+ * the reference lines whose work it replaces, and INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add at that line.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative DH_E* code; the text of
+ *     the last failure on the calling thread is dh_last_error();
+ *   - "dev" pointers are device (HBM) addresses owned by the caller, "host"
+ *     pointers are ordinary host memory; nothing is retained past the call
+ *     unless stated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); device
+ *     work is enqueued, never synchronised, unless stated;
+ *   - no torch types, no C++ types: plain pointers and sizes only.
+ */
+#ifndef DEEPHISTO_HIP_H
+#define DEEPHISTO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_OK 0
+#define DH_EINVAL (-22)  /* bad argument (shape, alignment, null pointer) */
+#define DH_ENOMEM (-12)  /* device or host allocation failed */
+#define DH_EHIP (-5)     /* a HIP runtime call or kernel launch failed */
+#define DH_ENOSYS (-38)  /* entry point not available in this build */
+
+/* layouts / dtypes of gathered tiles */
+#define DH_LAYOUT_NHWC 0 /* [n, P, P, 3]  (FullImageDenseSampler.generator_torch) */
+#define DH_LAYOUT_NCHW 1 /* [n, 3, P, P]  (batch_predictor's model input)          */
+#define DH_DTYPE_F32 0
+#define DH_DTYPE_BF16 1
+
+int dh_abi_version(void);
+const char* dh_last_error(void);
+
+/* ---- a1: tile-origin grid (host, integer) -------------------------------
+ * Replaces FullImageDenseSampler._create_batched_coords,
+ * patch_samplers/full_samplers.py:374-404.  Order: interior grid (y-major) over
+ * range(0,h-P,S) x range(0,w-P,S), last column, last row, corner; then the list
+ * is padded with copies of the corner up to a multiple of `batch`.
+ * dh_tile_grid_count: *n_unique = origins before padding, *n_padded = after.
+ * dh_tile_grid: writes n_padded (y,x) int32 pairs to host memory out_yx. */
+int dh_tile_grid_count(int64_t h, int64_t w, int32_t patch, int32_t stride, int32_t batch,
+                       int64_t* n_unique, int64_t* n_padded);
+int dh_tile_grid(int64_t h, int64_t w, int32_t patch, int32_t stride, int32_t batch,
+                 int32_t* out_yx_host, int64_t capacity_pairs);
+
+/* ---- synthetic slide (device) -------------------------------------------
+ * Fills slide_dev[h][w][3] (uint8, HWC, row pitch w*3) with the closed-form
+ * benchmark slide (formula frozen in oracle/synth.py / DESIGN.md).  The reference
+ * reads real slides via psimage (full_samplers.py:328-330); this is bench input. */
+int dh_synth_slide(uint8_t* slide_dev, int64_t h, int64_t w, uint32_t seed, void* stream);
+
+/* ---- a2/a4/a5: tile gather + /255 + layout --------------------------------
+ * Replaces _generate_batch_memory (full_samplers.py:353-369) + the feature
+ * build of generator_torch (full_samplers.py:441-443; NHWC f32) or of
+ * batch_predictor (examples/predict_full_patched.py:67-71; NCHW f32).
+ * slide_dev: uint8[h][w][3]; yx_dev: int32[n][2] (y,x) origins on device;
+ * out_dev: n*P*P*3 elements of `dtype` in `layout`.  Values are exactly
+ * float32(k)/255 (bit-exact with NumPy), rounded to nearest-even for bf16.
+ * Origins must satisfy 0 <= y <= h-P, 0 <= x <= w-P (checked on host only when
+ * yx_host_check != NULL, which must then hold the same n pairs). */
+int dh_tile_gather(const uint8_t* slide_dev, int64_t h, int64_t w, const int32_t* yx_dev,
+                   const int32_t* yx_host_check, int64_t n, int32_t patch, int32_t layout,
+                   int32_t dtype, void* out_dev, void* stream);
+
+/* coords tensor of generator_torch (full_samplers.py:444-451): float32[n][2]. */
+int dh_tile_coords_f32(const int32_t* yx_dev, int64_t n, float* out_dev, void* stream);
+
+/* ---- a8: logit accumulation + argmax ------------------------------------
+ * Replaces the per-patch `prediction[y//d:(y+P)//d, x//d:(x+P)//d, :] += logits[i]`
+ * loop and the final argmax of ImagePredictorPatched.process
+ * (examples/predict_full_patched.py:41-62).  Tiles are applied in list order
+ * (duplicates included) with one float32 add each, so the canvas is bit-exact
+ * with NumPy for identical logits.  yx_host: int32[n][2] host copy of origins;
+ * logits_dev: float32[n][n_cls]; canvas_dev: float32[dh][dw][n_cls] (accumulated
+ * into -- zero it first for a fresh prediction), dh = h/d, dw = w/d (floor).
+ * map_dev (optional, may be NULL): int64[dh][dw] = first index of the maximum
+ * over classes of the updated canvas (NumPy argmax tie/NaN rule). */
+int dh_accumulate_logits(const float* logits_dev, const int32_t* yx_host, int64_t n,
+                         int32_t patch, int32_t downscale, int32_t n_cls, int64_t h, int64_t w,
+                         float* canvas_dev, int64_t* map_dev, void* stream);
+int dh_argmax_map(const float* canvas_dev, int64_t n_cells, int32_t n_cls, int64_t* map_dev,
+                  void* stream);
+
+/* ---- a6: ResNet-18 patch classifier forward ---------------------------------
+ * Replaces `model(features)` for the network built by get_model
+ * (models/patch_cls_simple/model.py:5-11: torchvision resnet18 + fc[n_cls,512])
+ * in eval mode, as called from batch_predictor (predict_full_patched.py:77).
+ * A handle owns device copies of the parameters (packed for MFMA) and the
+ * activation workspace; one handle per thread/stream.
+ * compute dtype: DH_DTYPE_F32 (f32 MFMA, logits within 1e-4 of the CPU path) or
+ * DH_DTYPE_BF16 (bf16 MFMA, f32 accumulate). */
+typedef struct dh_resnet18 dh_resnet18;
+int dh_resnet18_create(dh_resnet18** out, int32_t n_classes, int32_t compute_dtype);
+void dh_resnet18_destroy(dh_resnet18* net);
+/* Set one parameter/buffer by its torchvision state_dict name ("conv1.weight",
+ * "layer2.0.downsample.1.running_var", "fc.bias", ...).  data_host: float32,
+ * n_elem must match.  "num_batches_tracked" entries are accepted and ignored. */
+int dh_resnet18_set_param(dh_resnet18* net, const char* name, const float* data_host,
+                          int64_t n_elem);
+/* Call after all parameters are set (or changed): folds BN running stats into
+ * per-channel scale/shift and packs conv weights into MFMA fragment order. */
+int dh_resnet18_finalize(dh_resnet18* net, void* stream);
+/* x_dev: float32[n][3][P][P] NCHW in [0,1] (what batch_predictor feeds the model);
+ * logits_dev: float32[n][n_classes].  P must be a multiple of 32. */
+int dh_resnet18_forward(dh_resnet18* net, const float* x_dev, int64_t n, int32_t patch,
+                        float* logits_dev, void* stream);
+/* Fused a2+a5+a6: gathers the tiles straight from the uint8 slide inside the
+ * stem kernel (no float copy of the pixels is ever written to HBM). */
+int dh_resnet18_forward_tiles(dh_resnet18* net, const uint8_t* slide_dev, int64_t h, int64_t w,
+                              const int32_t* yx_dev, int64_t n, int32_t patch,
+                              float* logits_dev, void* stream);
+
+/* ---- debug / test hooks (not part of the drop-in boundary) ---------------------
+ * dh_debug_conv_bn_act: one conv (ks in {1,3}, pad ks/2) + per-channel scale/shift
+ * (+ residual) (+ ReLU) on NHWC data of `dtype`; weights are float32
+ * [cout][cin][ks][ks] on the host.  Synchronises the stream.
+ * dh_debug_stem_out: float32 NHWC copy of the stem activation (conv1+bn1+relu) left
+ * in the workspace by the last forward of n tiles of size P. */
+int dh_debug_conv_bn_act(const void* in_dev, const float* w_host, const float* scale_host,
+                         const float* shift_host, const void* res_dev, void* out_dev, int32_t B,
+                         int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t ks, int32_t stride,
+                         int32_t relu, int32_t dtype, void* stream);
+int dh_debug_stem_out(dh_resnet18* net, int64_t n, int32_t patch, float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPHISTO_HIP_H */
