@@ -8,6 +8,13 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+# torch must be imported BEFORE the library is dlopen'ed: torch bundles its own HIP
+# runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and our library has to bind
+# to that same runtime instance -- the device pointers and hipStream_t handles it receives
+# come from torch.  Loading ours first would pull in /opt/rocm's copy instead and leave the
+# process with a runtime torch cannot use ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 LIB_PATH = Path(__file__).resolve().parent / "libdeephisto_hip.so"
 
 DH_LAYOUT_NHWC, DH_LAYOUT_NCHW = 0, 1
@@ -35,6 +42,8 @@ SIGNATURES = {
     "dh_resnet18_forward_tiles": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _p, _p]),
     "dh_debug_conv_bn_act": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i32] * 9 + [_p]),
     "dh_debug_stem_out": (C.c_int, [_p, _i64, _i32, _p, _p]),
+    "dh_profile_start": (C.c_int, [_i32, _i32]),
+    "dh_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
 }
 
 

@@ -585,6 +585,17 @@ void pack_stem_weights(const float* w, int esz, std::vector<uint8_t>& out) {
   }
 }
 
+// Optional in-library timing of the dominant kernel (3x3 stride-1 conv): HIP events on
+// the launch stream around sampled launches, summed by dh_profile_stop (bench.py's
+// `roofline.achieved`).  Off by default; costs nothing when off.
+struct Profiler {
+  bool on = false;
+  int every = 1, counter = 0;
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+  double flops = 0.0;
+} g_prof;
+
 template <typename T, int KS, int STRIDE, bool HALO>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   const int npx_lds = HALO ? p.IMGS * (p.TH + 2) * (p.TW + 2) : 256;
@@ -598,8 +609,18 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
+  bool sample = false;
+  if (HALO && g_prof.on && g_prof.used + 2 <= g_prof.ev.size() && (g_prof.counter++ % g_prof.every) == 0) {
+    sample = true;
+    DH_HIP(hipEventRecord(g_prof.ev[g_prof.used], st));
+  }
   hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, HALO>), dim3(grid), dim3(256), lds, st, p);
   DH_LAUNCH_CHECK();
+  if (sample) {
+    DH_HIP(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
+    g_prof.used += 2;
+    g_prof.flops += 2.0 * p.B * p.Ho * p.Wo * (double)p.Cout * KS * KS * p.Cin;
+  }
   return DH_OK;
 }
 
@@ -797,7 +818,7 @@ extern "C" int dh_resnet18_finalize(dh_resnet18* net, void* stream) {
 }
 
 static int check_forward_args(dh_resnet18* net, int64_t n, int32_t P, const void* logits) {
-  DH_REQUIRE(net && logits, "resnet18 forward: null argument");
+  DH_REQUIRE(net && (logits || n == 0), "resnet18 forward: null argument");
   DH_REQUIRE(net->finalized, "resnet18 forward: call dh_resnet18_finalize after setting parameters");
   DH_REQUIRE(n >= 0 && n <= 4096, "resnet18 forward: batch %lld out of range [0, 4096]", (long long)n);
   DH_REQUIRE(P >= 32 && P <= 1024, "resnet18 forward: patch %d out of range [32, 1024]", P);
@@ -808,8 +829,8 @@ extern "C" int dh_resnet18_forward(dh_resnet18* net, const float* x, int64_t n, 
                                    float* logits, void* stream) {
   int rc = check_forward_args(net, n, P, logits);
   if (rc) return rc;
-  DH_REQUIRE(x != nullptr, "resnet18 forward: null input");
   if (n == 0) return DH_OK;
+  DH_REQUIRE(x != nullptr, "resnet18 forward: null input");
   hipStream_t st = dh::as_stream(stream);
   return net->dtype == DH_DTYPE_F32
              ? forward_impl<float>(net, x, nullptr, 0, nullptr, n, P, logits, st)
@@ -821,10 +842,10 @@ extern "C" int dh_resnet18_forward_tiles(dh_resnet18* net, const uint8_t* slide,
                                          void* stream) {
   int rc = check_forward_args(net, n, P, logits);
   if (rc) return rc;
+  if (n == 0) return DH_OK;
   DH_REQUIRE(slide && yx, "resnet18 forward_tiles: null slide or origins");
   DH_REQUIRE(h >= P && w >= P, "resnet18 forward_tiles: patch %d does not fit %lldx%lld", P,
              (long long)h, (long long)w);
-  if (n == 0) return DH_OK;
   hipStream_t st = dh::as_stream(stream);
   return net->dtype == DH_DTYPE_F32
              ? forward_impl<float>(net, nullptr, slide, w, yx, n, P, logits, st)
@@ -888,5 +909,35 @@ extern "C" int dh_debug_stem_out(dh_resnet18* net, int64_t n, int32_t P, float* 
   else
     hipLaunchKernelGGL((to_f32_kernel<__bf16>), dim3(1024), dim3(256), 0, st, static_cast<const __bf16*>(net->ws), out_dev, elems);
   DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// dominant-kernel timing (see Profiler above)
+// ---------------------------------------------------------------------------
+extern "C" int dh_profile_start(int32_t sample_every, int32_t max_samples) {
+  DH_REQUIRE(sample_every > 0 && max_samples > 0 && max_samples <= (1 << 20), "profile start: bad arguments");
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.assign((size_t)max_samples * 2, nullptr);
+  for (auto& e : g_prof.ev) DH_HIP(hipEventCreate(&e));
+  g_prof.every = sample_every; g_prof.counter = 0; g_prof.used = 0; g_prof.flops = 0.0;
+  g_prof.on = true;
+  return DH_OK;
+}
+
+extern "C" int dh_profile_stop(double* total_ms, double* total_flops, int64_t* n_samples) {
+  g_prof.on = false;
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    DH_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+    float t = 0.f;
+    DH_HIP(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+    ms += t;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = g_prof.flops;
+  if (n_samples) *n_samples = (int64_t)(g_prof.used / 2);
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear(); g_prof.used = 0;
   return DH_OK;
 }

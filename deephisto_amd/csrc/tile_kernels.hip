@@ -239,13 +239,13 @@ __global__ __launch_bounds__(256) void gather_generic_kernel(const uint8_t* __re
 extern "C" int dh_tile_gather(const uint8_t* slide, int64_t h, int64_t w, const int32_t* yx_dev,
                               const int32_t* yx_host_check, int64_t n, int32_t P, int32_t layout,
                               int32_t dtype, void* out, void* stream) {
+  DH_REQUIRE(n >= 0 && n <= 65535, "tile gather: n=%lld out of range [0, 65535]", (long long)n);
+  if (n == 0) return DH_OK;  // empty batch: nothing to read or write (pointers may be null)
   DH_REQUIRE(slide && yx_dev && out, "tile gather: null pointer");
   DH_REQUIRE(P > 0 && h >= P && w >= P, "tile gather: patch %d does not fit %lldx%lld", P,
              (long long)h, (long long)w);
   DH_REQUIRE(layout == DH_LAYOUT_NHWC || layout == DH_LAYOUT_NCHW, "tile gather: bad layout %d", layout);
   DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "tile gather: bad dtype %d", dtype);
-  DH_REQUIRE(n >= 0 && n <= 65535, "tile gather: n=%lld out of range [0, 65535]", (long long)n);
-  if (n == 0) return DH_OK;
   if (yx_host_check)
     for (int64_t i = 0; i < n; ++i) {
       const int64_t y = yx_host_check[2 * i], x = yx_host_check[2 * i + 1];
@@ -288,8 +288,8 @@ __global__ void coords_kernel(const int32_t* __restrict__ yx, int64_t n2, float*
 }
 
 extern "C" int dh_tile_coords_f32(const int32_t* yx_dev, int64_t n, float* out, void* stream) {
-  DH_REQUIRE(yx_dev && out && n >= 0, "tile coords: bad arguments");
   if (n == 0) return DH_OK;
+  DH_REQUIRE(yx_dev && out && n > 0, "tile coords: bad arguments");
   hipLaunchKernelGGL(coords_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0,
                      dh::as_stream(stream), yx_dev, 2 * n, out);
   DH_LAUNCH_CHECK();

@@ -16,8 +16,10 @@ from typing import Callable
 import numpy as np
 import torch
 
+import ctypes as C
+
 from .. import tiles
-from .._lib import DH_LAYOUT_NCHW
+from .._lib import DH_LAYOUT_NCHW, check, lib
 from ..models.patch_cls_simple.model import ResNet18HIP, get_model
 from ..patch_samplers.full_samplers import DevicePatch, FullImageDenseSampler
 from ..psimage_compat import Patch, open_slide
@@ -152,9 +154,14 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     o_dev = torch.from_numpy(origins[lo:hi]).to(dev)
     per_rank = -(-n_unique // world)
     local = torch.zeros((per_rank, n_classes), dtype=torch.float32, device=dev)
+    # parameters are synced to the native handle once; the loop below is launches only
+    handle = model.eval()._ensure_handle()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    fwd = lib().dh_resnet18_forward_tiles
     for s in range(0, hi - lo, mb):
         e = min(s + mb, hi - lo)
-        local[s:e] = model.forward_tiles(slide, o_dev[s:e].contiguous(), P)
+        check(fwd(handle, slide.data_ptr(), sampler.h, sampler.w, o_dev.data_ptr() + 8 * s, e - s, P,
+                  local.data_ptr() + 4 * n_classes * s, stream), "dh_resnet18_forward_tiles")
     if distributed:
         gathered = torch.empty((world * per_rank, n_classes), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(gathered, local, group=group)

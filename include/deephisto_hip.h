@@ -133,6 +133,14 @@ int dh_debug_conv_bn_act(const void* in_dev, const float* w_host, const float* s
                          int32_t relu, int32_t dtype, void* stream);
 int dh_debug_stem_out(dh_resnet18* net, int64_t n, int32_t patch, float* out_dev, void* stream);
 
+/* ---- measurement -----------------------------------------------------------------
+ * Times the dominant kernel (3x3 stride-1 conv, ~85 % of the model FLOPs) with HIP
+ * events recorded on the launch stream around every `sample_every`-th launch (at most
+ * max_samples).  dh_profile_stop waits for the sampled launches and returns the summed
+ * kernel time, the summed algorithmic FLOPs (2*pixels*cout*9*cin) and the sample count. */
+int dh_profile_start(int32_t sample_every, int32_t max_samples);
+int dh_profile_stop(double* total_ms, double* total_flops, int64_t* n_samples);
+
 #ifdef __cplusplus
 }
 #endif

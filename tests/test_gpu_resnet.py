@@ -1,0 +1,145 @@
+"""GPU parity, model side (row a6): HIP ResNet-18 forward vs the torch-CPU oracle.
+
+Tolerances (floating point, stated per BASELINE.json north_star):
+  f32 compute: |logit - oracle| <= 1e-4 absolute;
+  bf16 compute: <= 3e-2 * max(1, max|logit|)  (bf16 has 8 significant bits; activations
+  are re-rounded after each of 20 convs).
+The oracle is "parity unpinned" against torchvision (see oracle/resnet18.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import resnet18 as oracle_net
+from oracle import synth, tiling
+
+pytestmark = pytest.mark.gpu
+
+F32_ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev(built_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _hip_model(oracle, dev, dtype="f32"):
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    m = get_model(5, compute_dtype=dtype)
+    missing, unexpected = m.load_state_dict(oracle.state_dict(), strict=True)
+    return m.to(dev).eval()
+
+
+def test_state_dict_keys_match_torchvision_layout():
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    a = get_model(5).state_dict()
+    b = oracle_net.ResNet18Oracle(5).state_dict()
+    assert list(a.keys()) == list(b.keys())
+    assert all(a[k].shape == b[k].shape for k in a)
+    assert "layer2.0.downsample.1.running_var" in a and a["fc.weight"].shape == (5, 512)
+    assert sum(v.numel() for k, v in a.items() if "running" not in k and "tracked" not in k) == 11179077
+
+
+@pytest.mark.parametrize("dtype,ks,stride,cin,cout,hw", [
+    ("f32", 3, 1, 64, 64, 32), ("f32", 3, 2, 64, 128, 32), ("f32", 1, 2, 64, 128, 32),
+    ("f32", 3, 1, 128, 128, 14), ("f32", 3, 1, 512, 512, 8), ("f32", 3, 1, 512, 512, 7),
+    ("bf16", 3, 1, 64, 64, 32), ("bf16", 3, 2, 128, 256, 28), ("bf16", 1, 2, 256, 512, 16),
+    ("bf16", 3, 1, 256, 256, 16),
+])
+def test_single_conv_layer(dev, dtype, ks, stride, cin, cout, hw):
+    """One conv + scale/shift + residual + ReLU through dh_debug_conv_bn_act."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(ks * 1000 + cin + hw)
+    B = 3
+    x = torch.randn(B, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    sc = 0.5 + torch.rand(cout, generator=g)
+    sh = 0.2 * torch.randn(cout, generator=g)
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    if dtype == "bf16":
+        x, w = x.to(tdt).float(), w.to(tdt).float()
+    y = F.conv2d(x, w, None, stride, ks // 2)
+    res = torch.randn(y.shape, generator=g).to(tdt).float()
+    want = F.relu(y * sc[None, :, None, None] + sh[None, :, None, None] + res)
+    x_d = x.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+    r_d = res.permute(0, 2, 3, 1).contiguous().to(dev, tdt)
+    out = torch.empty((B, y.shape[2], y.shape[3], cout), dtype=tdt, device=dev)
+    wc, scc, shc = w.contiguous(), sc.contiguous(), sh.contiguous()
+    check(lib().dh_debug_conv_bn_act(x_d.data_ptr(), wc.data_ptr(), scc.data_ptr(), shc.data_ptr(), r_d.data_ptr(),
+                                     out.data_ptr(), B, hw, hw, cin, cout, ks, stride, 1,
+                                     0 if dtype == "f32" else 1, None), "dh_debug_conv_bn_act")
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    tol = 2e-5 * max(1.0, float(want.abs().max())) if dtype == "f32" else 1e-2 * max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("P,B", [(256, 4), (224, 3), (96, 2)])
+def test_resnet18_f32_logits_within_1e4(dev, P, B):
+    oracle = oracle_net.seeded_model(123, 5, perturb_bn=True).eval()
+    model = _hip_model(oracle, dev, "f32")
+    host = synth.synth_slide(P + 40, P * B + 17, seed=P)
+    o = np.array([[7 + 3 * i, 5 + i * P] for i in range(B)], np.int32)
+    x = torch.from_numpy(tiling.features_nchw_predictor(host, o, P))
+    with torch.no_grad():
+        want = oracle(x)
+    got = model(x.to(dev))
+    # stem first, to localise failures
+    from deephisto_amd._lib import check, lib
+    H1 = (P - 1) // 2 + 1
+    stem = torch.empty((B, H1, H1, 64), dtype=torch.float32, device=dev)
+    check(lib().dh_debug_stem_out(model._handle, B, P, stem.data_ptr(), None), "dh_debug_stem_out")
+    with torch.no_grad():
+        stem_want = F.relu(oracle.bn1(oracle.conv1(x)))
+    err = float((stem.cpu().permute(0, 3, 1, 2) - stem_want).abs().max())
+    assert err <= 2e-5 * max(1.0, float(stem_want.abs().max())), f"stem error {err}"
+    err = float((got.cpu() - want).abs().max())
+    assert err <= F32_ATOL, f"max |logit error| = {err} (logit scale {float(want.abs().max())})"
+    # fused gather path gives the same logits (same kernels, pixels read from the uint8 slide)
+    slide = torch.from_numpy(host).to(dev)
+    got2 = model.forward_tiles(slide, torch.from_numpy(o).to(dev), P)
+    assert float((got2 - got).abs().max()) <= 1e-6
+
+
+def test_resnet18_f32_batch64_and_determinism(dev):
+    """B=64 (4-image patches in layer4 all full) and run-to-run bitwise determinism."""
+    oracle = oracle_net.seeded_model(5, 5, perturb_bn=True).eval()
+    model = _hip_model(oracle, dev, "f32")
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(10, 3, 128, 128, generator=g)
+    with torch.no_grad():
+        want = oracle(x)
+    a = model(x.to(dev))
+    b = model(x.to(dev))
+    assert torch.equal(a, b)
+    assert float((a.cpu() - want).abs().max()) <= F32_ATOL
+    # per-tile result does not depend on batch composition
+    c = model(x[3:7].to(dev))
+    assert torch.equal(c, a[3:7])
+
+
+def test_resnet18_bf16_logits(dev):
+    oracle = oracle_net.seeded_model(321, 5, perturb_bn=True).eval()
+    model = _hip_model(oracle, dev, "bf16")
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(6, 3, 256, 256, generator=g)
+    with torch.no_grad():
+        want = oracle(x)
+    got = model(x.to(dev)).cpu()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= 3e-2 * scale, f"bf16 logit error {err} at scale {scale}"
+
+
+def test_model_errors(dev):
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    m = get_model(5).to(dev)
+    with pytest.raises(NotImplementedError):
+        m.train()(torch.zeros(1, 3, 64, 64, device=dev))
+    m.eval()
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 4, 64, 64, device=dev))
