@@ -38,7 +38,8 @@ def _stale(target: Path, deps: list[Path]) -> bool:
 def build_library(force: bool = False, verbose: bool = True) -> Path:
     hipcc = _hipcc()
     srcs = sorted(CSRC.glob("*.hip"))
-    hdrs = sorted(CSRC.glob("*.h")) + sorted((PKG.parent / "include").glob("*.h")) + [Path(__file__)]
+    hdrs = (sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + sorted((PKG.parent / "include").glob("*.h"))
+            + [Path(__file__)])
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
 

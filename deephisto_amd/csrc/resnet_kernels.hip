@@ -23,6 +23,7 @@
 //  * LDS per workgroup <= 68 KiB and <= 128 VGPRs -> two workgroups per CU, one
 //    staging while the other issues MFMAs.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -249,6 +250,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
     }
   }
 }
+
+#include "conv3x3.inc"
 
 // ---------------------------------------------------------------------------
 // Stem: conv 7x7 / stride 2 / pad 3, 3 -> 64, + BN + ReLU, output NHWC.
@@ -609,17 +612,93 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
+  hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, HALO>), dim3(grid), dim3(256), lds, st, p);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+bool g_stamps_on = false;
+unsigned long long* g_stamps_dev = nullptr;
+void* g_zero_page = nullptr;  // 1 KiB of zeros: DMA source of padding pixels
+
+template <typename T, int STRIDE, int NT, int WAVES>
+int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
+  const int win_bytes = p.IMGS * p.HR * p.HP * CHUNK_BYTES;
+  const size_t buf = (size_t)9 * SLAB_TAP + ((win_bytes + 1023) & ~1023);
+  const size_t lds = 2 * buf + 1024;  // 2-deep ring + [2][scale|shift]
+  constexpr int MAXJ = (STRIDE == 2) ? 10 : (NT == 2 ? 6 : 4);
+  p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
+  DH_REQUIRE(p.n_win_instr <= MAXJ * WAVES, "conv3x3: staging window too large for the DMA plan");
+  DH_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS budget exceeded (%zu B)", lds);
+  DH_REQUIRE(p.IMGS * p.TH * p.TW == WAVES * NT * 32, "conv3x3: tile/pixel mismatch");
+  DH_REQUIRE(L.cin * (int)sizeof(T) >= 2 * CHUNK_BYTES, "conv3x3: needs at least two channel chunks");
+  const int groups = ((p.B + p.IMGS - 1) / p.IMGS) * p.tiles_y * p.tiles_x;
+  p.ntiles = groups * (L.cout / 64);
+  const int grid = std::min(256, p.ntiles);  // persistent: one workgroup per CU
+  p.iters = (p.ntiles + grid - 1) / grid;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+template <typename T, int STRIDE>
+int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* out, int B, int Hi, int Wi,
+                   bool relu, hipStream_t st, int Ho, int Wo) {
+  Conv3Params p;
+  p.in = in; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = out;
+  p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = L.cin; p.Cout = L.cout; p.Ho = Ho; p.Wo = Wo;
+  p.relu = relu ? 1 : 0;
+  if (!g_zero_page) {
+    DH_HIP(hipMalloc(&g_zero_page, 1024));
+    DH_HIP(hipMemset(g_zero_page, 0, 1024));
+  }
+  p.zero_page = g_zero_page;
+  p.stamps = nullptr;
+  if (g_stamps_on) {
+    if (!g_stamps_dev) {
+      DH_HIP(hipMalloc((void**)&g_stamps_dev, 64 * sizeof(unsigned long long)));
+      DH_HIP(hipMemset(g_stamps_dev, 0, 64 * sizeof(unsigned long long)));
+    }
+    // one row of 8 counters per layer class: rows 0..3 stride 1 by cin 64..512, 4..6 stride 2
+    const int row = (STRIDE == 1) ? (L.cin == 64 ? 0 : L.cin == 128 ? 1 : L.cin == 256 ? 2 : 3)
+                                  : (L.cin == 64 ? 4 : L.cin == 128 ? 5 : 6);
+    p.stamps = g_stamps_dev + 8 * row;
+  }
   bool sample = false;
-  if (HALO && g_prof.on && g_prof.used + 2 <= g_prof.ev.size() && (g_prof.counter++ % g_prof.every) == 0) {
+  if (STRIDE == 1 && g_prof.on && g_prof.used + 2 <= g_prof.ev.size() && (g_prof.counter++ % g_prof.every) == 0) {
     sample = true;
     DH_HIP(hipEventRecord(g_prof.ev[g_prof.used], st));
   }
-  hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, HALO>), dim3(grid), dim3(256), lds, st, p);
-  DH_LAUNCH_CHECK();
+  int rc;
+  if (STRIDE == 1) {
+    p.HPH = 0;
+    if (Wo > 16) { p.TH = 16; p.TW = 32; p.IMGS = 1; p.HP = 34; }
+    else if (Wo > 8) { p.TH = 16; p.TW = 16; p.IMGS = 2; p.HP = 18; }
+    else { p.TH = 8; p.TW = 8; p.IMGS = 4; p.HP = 10; }
+    p.HR = p.TH + 2; p.HC = p.TW + 2;
+    p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
+    rc = (Wo > 8) ? launch_conv3x3_cfg<T, 1, 2, 8>(p, L, st) : launch_conv3x3_cfg<T, 1, 1, 8>(p, L, st);
+  } else {
+    if (Wo > 8) { p.TH = 8; p.TW = 16; p.IMGS = 1; }
+    else { p.TH = 8; p.TW = 8; p.IMGS = 2; }
+    p.HR = 2 * p.TH + 1; p.HC = 2 * p.TW + 1; p.HPH = p.TW + 1; p.HP = 2 * p.HPH;
+    p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
+    rc = launch_conv3x3_cfg<T, 2, 1, 4>(p, L, st);
+  }
+  if (rc) return rc;
   if (sample) {
     DH_HIP(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
     g_prof.used += 2;
-    g_prof.flops += 2.0 * p.B * p.Ho * p.Wo * (double)p.Cout * KS * KS * p.Cin;
+    g_prof.flops += 2.0 * B * Ho * Wo * (double)L.cout * 9 * L.cin;
   }
   return DH_OK;
 }
@@ -627,21 +706,20 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
 template <typename T>
 int run_conv(const ConvLayer& L, const void* in, const void* res, void* out, int B, int Hi, int Wi,
              bool relu, hipStream_t st, int* Ho_out, int* Wo_out) {
+  const int pad = L.ks / 2;
+  const int Ho = (Hi + 2 * pad - L.ks) / L.stride + 1, Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
+  *Ho_out = Ho; *Wo_out = Wo;
+  DH_REQUIRE((int64_t)B * Hi * Wi * L.cin * (int64_t)sizeof(T) < ((int64_t)1 << 32),
+             "conv %s: input larger than 4 GiB, reduce the batch", L.name.c_str());
+  if (L.ks == 3 && L.stride == 1) return launch_conv3x3<T, 1>(L, in, res, out, B, Hi, Wi, relu, st, Ho, Wo);
+  if (L.ks == 3 && L.stride == 2) return launch_conv3x3<T, 2>(L, in, res, out, B, Hi, Wi, relu, st, Ho, Wo);
   ConvParams p;
   p.in = in; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = out;
-  p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = L.cin; p.Cout = L.cout;
-  const int pad = L.ks / 2;
-  p.Ho = (Hi + 2 * pad - L.ks) / L.stride + 1;
-  p.Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
+  p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = L.cin; p.Cout = L.cout; p.Ho = Ho; p.Wo = Wo;
   if (p.Ho > 8 || p.Wo > 8) { p.TH = 16; p.TW = 16; p.IMGS = 1; }
   else { p.TH = 8; p.TW = 8; p.IMGS = 4; }
   p.tiles_y = (p.Ho + p.TH - 1) / p.TH; p.tiles_x = (p.Wo + p.TW - 1) / p.TW;
   p.relu = relu ? 1 : 0;
-  *Ho_out = p.Ho; *Wo_out = p.Wo;
-  DH_REQUIRE((int64_t)B * Hi * Wi * L.cin * (int64_t)sizeof(T) < ((int64_t)1 << 32),
-             "conv %s: input larger than 4 GiB, reduce the batch", L.name.c_str());
-  if (L.ks == 3 && L.stride == 1) return launch_conv<T, 3, 1, true>(p, st);
-  if (L.ks == 3 && L.stride == 2) return launch_conv<T, 3, 2, false>(p, st);
   if (L.ks == 1 && L.stride == 2) return launch_conv<T, 1, 2, false>(p, st);
   dh::set_error("conv %s: unsupported shape", L.name.c_str());
   return DH_EINVAL;
@@ -939,5 +1017,18 @@ extern "C" int dh_profile_stop(double* total_ms, double* total_flops, int64_t* n
   if (n_samples) *n_samples = (int64_t)(g_prof.used / 2);
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
   g_prof.ev.clear(); g_prof.used = 0;
+  return DH_OK;
+}
+
+// Diagnostic phase stamps of the 3x3 conv kernel (DH tests/tools only): enable, then read
+// 8 rows x 8 counters {load-issue, mfma, barrier, epilogue, lds-write, barrier, workgroups, -}.
+extern "C" int dh_debug_stamps(int32_t enable, unsigned long long* out64_host) {
+  g_stamps_on = enable != 0;
+  if (out64_host) {
+    if (!g_stamps_dev) { memset(out64_host, 0, 64 * sizeof(unsigned long long)); return DH_OK; }
+    DH_HIP(hipDeviceSynchronize());
+    DH_HIP(hipMemcpy(out64_host, g_stamps_dev, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    DH_HIP(hipMemset(g_stamps_dev, 0, 64 * sizeof(unsigned long long)));
+  }
   return DH_OK;
 }

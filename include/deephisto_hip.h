@@ -132,6 +132,9 @@ int dh_debug_conv_bn_act(const void* in_dev, const float* w_host, const float* s
                          int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t ks, int32_t stride,
                          int32_t relu, int32_t dtype, void* stream);
 int dh_debug_stem_out(dh_resnet18* net, int64_t n, int32_t patch, float* out_dev, void* stream);
+/* dh_debug_stamps: switch the 3x3-conv kernel to its cycle-stamped diagnostic variant and/or read
+ * (and clear) its 8x8 table of summed phase cycles; out64_host may be NULL. */
+int dh_debug_stamps(int32_t enable, unsigned long long* out64_host);
 
 /* ---- measurement -----------------------------------------------------------------
  * Times the dominant kernel (3x3 stride-1 conv, ~85 % of the model FLOPs) with HIP
