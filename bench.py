@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--stride", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64, help="sampler batch size (grid padding unit)")
     ap.add_argument("--micro-batch", type=int, default=128, help="tiles per kernel launch")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams (micro-batches in flight)")
     ap.add_argument("--downscale", type=int, default=16)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--seed", type=int, default=0)
@@ -56,13 +57,26 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, budget_s: float) -> dict:
     """The oracle (port of the reference's CPU path a1->a8) on a bounded sample: the first
     tiles of a 4096x4096 closed-form slide, whole batches, until the budget is spent."""
     from oracle import resnet18 as oracle_net
     from oracle import synth, tiling
 
-    threads = torch.get_num_threads()
+    threads = host_cores()
+    torch.set_num_threads(threads)
     side = 4096
     host = synth.synth_slide(side, side, args.seed)
     net = oracle_net.seeded_model(0, 5).eval()
@@ -118,7 +132,8 @@ def main():
     n_tiles = smp.n_tiles
 
     def step():
-        return predict_full_patched(smp, model, 5, downscale=args.downscale, micro_batch=args.micro_batch)
+        return predict_full_patched(smp, model, 5, downscale=args.downscale, micro_batch=args.micro_batch,
+                                    streams=args.streams)
 
     def fence():
         if world > 1:
@@ -159,11 +174,11 @@ def main():
                                    "step = one whole slide (tile grid -> fused gather+forward -> all-gather -> "
                                    "ordered accumulate -> argmax)",
                        "slide_hw": [side, side], "patch": args.patch, "stride": args.stride,
-                       "sampler_batch": args.batch, "micro_batch": args.micro_batch, "downscale": args.downscale,
+                       "sampler_batch": args.batch, "micro_batch": args.micro_batch, "streams": args.streams, "downscale": args.downscale,
                        "n_tiles": n_tiles, "n_classes": 5,
                        "parallelism": f"tile-range shard x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
             "model_tflops": value * flop_tile / 1e12,
-            "roofline": {"bound": "mfma", "kernel": f"conv_kernel<{args.dtype},3x3,s1,halo>",
+            "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<{args.dtype}, stride 1, NT=2, 8 waves> (layers 1-3, 10 of 20 convs)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
                          "launches_timed": int(k_n.value),

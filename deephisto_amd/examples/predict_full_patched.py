@@ -124,9 +124,44 @@ def shard_range(n_items: int, world: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(dev, i):
+    key = (dev.index, i)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
+def exchange_logits(local: torch.Tensor, n_unique: int, group=None) -> torch.Tensor:
+    """The one exchange step of the sharded path: all-gather of per-tile logits.
+
+    `local` is this rank's float32[ceil(n_unique/world), n_cls] block (its first
+    hi-lo rows are real, the rest padding); returns float32[n_unique, n_cls] in the
+    reference's tile order on every rank.  RCCL (backend "nccl") on GPUs; the same
+    code runs on gloo/CPU tensors in the tests."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    per_rank = local.shape[0]
+    gathered = torch.empty((world * per_rank, local.shape[1]), dtype=local.dtype, device=local.device)
+    try:
+        dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):  # backends without the flat form
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local.contiguous(), group=group)
+        gathered = torch.cat(parts)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(n_unique, world, r)
+        rows.append(gathered[r * per_rank:r * per_rank + (hi - lo)])
+    return torch.cat(rows)
+
+
 def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_classes: int,
                          downscale: int = 16, micro_batch: int | None = None, group=None,
-                         return_logits: bool = False):
+                         return_logits: bool = False, streams: int = 2):
     """Device-resident whole-slide prediction (rows a1-a8 end to end).
 
     Single process: every tile (padding duplicates included) goes through the fused
@@ -154,24 +189,24 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     o_dev = torch.from_numpy(origins[lo:hi]).to(dev)
     per_rank = -(-n_unique // world)
     local = torch.zeros((per_rank, n_classes), dtype=torch.float32, device=dev)
-    # parameters are synced to the native handle once; the loop below is launches only
-    handle = model.eval()._ensure_handle()
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    # parameters are synced to the native handles once; the loop below is launches only.
+    # Micro-batches alternate over `streams` HIP streams (one workspace each) so that the short
+    # kernels and the tails of one micro-batch overlap with the convolutions of the next.
+    handles = model.eval().lane_handles(max(1, streams))
+    main = torch.cuda.current_stream(dev)
+    lanes = [main] + [_side_stream(dev, i) for i in range(1, len(handles))]
+    for st in lanes[1:]:
+        st.wait_stream(main)
     fwd = lib().dh_resnet18_forward_tiles
-    for s in range(0, hi - lo, mb):
+    for k, s in enumerate(range(0, hi - lo, mb)):
         e = min(s + mb, hi - lo)
-        check(fwd(handle, slide.data_ptr(), sampler.h, sampler.w, o_dev.data_ptr() + 8 * s, e - s, P,
-                  local.data_ptr() + 4 * n_classes * s, stream), "dh_resnet18_forward_tiles")
-    if distributed:
-        gathered = torch.empty((world * per_rank, n_classes), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(gathered, local, group=group)
-        parts = []
-        for r in range(world):
-            rl, rh = shard_range(n_unique, world, r)
-            parts.append(gathered[r * per_rank:r * per_rank + (rh - rl)])
-        logits_unique = torch.cat(parts)
-    else:
-        logits_unique = local[:n_unique]
+        lane = k % len(handles)
+        check(fwd(handles[lane], slide.data_ptr(), sampler.h, sampler.w, o_dev.data_ptr() + 8 * s, e - s, P,
+                  local.data_ptr() + 4 * n_classes * s, C.c_void_p(lanes[lane].cuda_stream)),
+              "dh_resnet18_forward_tiles")
+    for st in lanes[1:]:
+        main.wait_stream(st)
+    logits_unique = exchange_logits(local, n_unique, group) if distributed else local[:n_unique]
     pad = n_padded - n_unique
     logits = torch.cat([logits_unique, logits_unique[-1:].expand(pad, -1)]) if pad else logits_unique
     _, cmap = tiles.accumulate_logits(logits.contiguous(), origins, P, downscale, sampler.h, sampler.w)

@@ -59,6 +59,7 @@ class ResNet18HIP(nn.Module):
                 nn.init.constant_(m.bias, 0)
         self._handle = None
         self._synced = None  # signature of the parameter versions held by the handle
+        self._lanes = []     # extra native handles (own workspace each) for multi-stream inference
 
     # ---- native handle management -------------------------------------------------
     def _signature(self):
@@ -82,6 +83,28 @@ class ResNet18HIP(nn.Module):
             self._synced = sig
         return self._handle
 
+    def lane_handles(self, n: int):
+        """n native handles holding the current parameters, each with its own activation
+        workspace, so that n micro-batches can be in flight on n HIP streams."""
+        first = self._ensure_handle()
+        sig = self._synced
+        while len(self._lanes) < n - 1:
+            self._lanes.append([C.c_void_p(), None])
+        for lane in self._lanes[:n - 1]:
+            if lane[1] != sig:
+                if not lane[0]:
+                    code = DH_DTYPE_F32 if self.compute_dtype == "f32" else DH_DTYPE_BF16
+                    check(lib().dh_resnet18_create(C.byref(lane[0]), self.n_classes, code), "dh_resnet18_create")
+                for name, t in self.state_dict().items():
+                    if name.endswith("num_batches_tracked"):
+                        continue
+                    a = t.detach().to("cpu", torch.float32).contiguous()
+                    check(lib().dh_resnet18_set_param(lane[0], name.encode(), a.data_ptr(), a.numel()),
+                          f"dh_resnet18_set_param({name})")
+                check(lib().dh_resnet18_finalize(lane[0], None), "dh_resnet18_finalize")
+                lane[1] = sig
+        return [first] + [lane[0] for lane in self._lanes[:n - 1]]
+
     def set_compute_dtype(self, compute_dtype: str):
         if compute_dtype != self.compute_dtype:
             self._release()
@@ -92,6 +115,10 @@ class ResNet18HIP(nn.Module):
         if getattr(self, "_handle", None) is not None:
             lib().dh_resnet18_destroy(self._handle)
             self._handle, self._synced = None, None
+        for lane in getattr(self, "_lanes", []):
+            if lane[0]:
+                lib().dh_resnet18_destroy(lane[0])
+        self._lanes = []
 
     def __del__(self):
         try:
