@@ -272,6 +272,7 @@ struct StemParams {
   const float* x_nchw; const uint8_t* slide; const int32_t* yx; int64_t row_bytes;
   const void* w; const float* scale; const float* shift; void* out;
   int B, P, Ho, Wo, tiles_y, tiles_x;
+  int relu;
 };
 
 template <typename T, bool SRC_U8>
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int co = mt * 32 + g * 8 + 4 * h;
-          store_group<T>(acc[mt][nt], g, p.scale, p.shift, (const T*)nullptr, out, pix * 64 + co, co, true);
+          store_group<T>(acc[mt][nt], g, p.scale, p.shift, (const T*)nullptr, out, pix * 64 + co, co, p.relu != 0);
         }
     }
   }
@@ -504,7 +505,9 @@ inline uint16_t host_bf16(float f) {
 
 }  // namespace
 
+struct dh_train;
 struct dh_resnet18 {
+  dh_train* train = nullptr;  // training state (train.inc), owned
   int n_classes = 0;
   int dtype = DH_DTYPE_F32;
   std::map<std::string, std::vector<float>> params;  // host copies by state_dict name
@@ -773,7 +776,7 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
     StemParams sp;
     sp.x_nchw = x; sp.slide = slide; sp.yx = yx; sp.row_bytes = slide_w * 3;
     sp.w = net->convs[0].w_dev; sp.scale = net->convs[0].scale_dev; sp.shift = net->convs[0].shift_dev;
-    sp.out = S; sp.B = B; sp.P = P; sp.Ho = H1; sp.Wo = H1;
+    sp.out = S; sp.B = B; sp.P = P; sp.Ho = H1; sp.Wo = H1; sp.relu = 1;
     sp.tiles_y = (H1 + STEM_TH - 1) / STEM_TH; sp.tiles_x = (H1 + STEM_TW - 1) / STEM_TW;
     const size_t wb = esz == 2 ? (size_t)7 * 2 * 2 * FRAG_BYTES : (size_t)7 * 11 * 2 * 256;
     const size_t lds = wb + (size_t)STEM_ROWS * STEM_ROWE * esz;
@@ -848,8 +851,10 @@ extern "C" int dh_resnet18_create(dh_resnet18** out, int32_t n_classes, int32_t 
   return DH_OK;
 }
 
+extern "C" int dh_resnet18_train_end(dh_resnet18* net);
 extern "C" void dh_resnet18_destroy(dh_resnet18* net) {
   if (!net) return;
+  if (net->train) (void)dh_resnet18_train_end(net);
   for (auto& c : net->convs) {
     if (c.w_dev) (void)hipFree(c.w_dev);
     if (c.scale_dev) (void)hipFree(c.scale_dev);
@@ -1052,3 +1057,5 @@ extern "C" int dh_debug_stamps(int32_t enable, unsigned long long* out64_host) {
   }
   return DH_OK;
 }
+
+#include "train.inc"

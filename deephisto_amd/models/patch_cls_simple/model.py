@@ -35,6 +35,22 @@ class _BlockParams(nn.Module):
                                             nn.BatchNorm2d(cout))
 
 
+class _TrainForward(torch.autograd.Function):
+    """logits = model(x) in training mode; backward runs the HIP backward kernels and hands
+    every parameter its gradient (so `loss.backward(); optimizer.step()` of
+    models/patch_cls_simple/train.py:171-172 work unchanged on the nn.Parameters)."""
+
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        ctx.model, ctx.x = model, x  # x must outlive backward (the stem wgrad reads it)
+        return model._native_forward_train(x)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        grads = ctx.model._native_backward(dlogits.contiguous())
+        return (None, None, *grads)
+
+
 class ResNet18HIP(nn.Module):
     """ResNet-18 patch classifier; forward = dh_resnet18_forward (gfx950 MFMA kernels)."""
 
@@ -112,6 +128,7 @@ class ResNet18HIP(nn.Module):
         return self
 
     def _release(self):
+        self._train_shape = None
         if getattr(self, "_handle", None) is not None:
             lib().dh_resnet18_destroy(self._handle)
             self._handle, self._synced = None, None
@@ -130,21 +147,111 @@ class ResNet18HIP(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: float32[n, 3, P, P] on the GPU (what batch_predictor builds,
         predict_full_patched.py:67-71) -> float32[n, n_classes] raw logits."""
-        if self.training:
-            raise NotImplementedError(
-                "ResNet18HIP: training-mode forward/backward kernels are not built yet "
-                "(SURVEY section 8 row a7); call .eval() for inference")
         if not x.is_cuda:
             raise RuntimeError("ResNet18HIP runs on the GPU only: move the input with .to('cuda')")
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3]:
             raise ValueError(f"expected [n, 3, P, P], got {tuple(x.shape)}")
         x = x.detach().to(torch.float32).contiguous()
+        if self.training:
+            if self.compute_dtype != "f32":
+                raise NotImplementedError("training kernels are float32 only in this build")
+            if torch.is_grad_enabled():
+                return _TrainForward.apply(x, self, *self.parameters())
+            return self._native_forward_train(x)  # e.g. train-mode forward under no_grad
         h = self._ensure_handle()
         n, p = int(x.shape[0]), int(x.shape[2])
         out = torch.empty((n, self.n_classes), dtype=torch.float32, device=x.device)
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         check(lib().dh_resnet18_forward(h, x.data_ptr(), n, p, out.data_ptr(), stream), "dh_resnet18_forward")
         return out
+
+    # ---- training (row a7): HIP forward/backward behind torch autograd ---------------------
+    def _stream(self, dev):
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def _push_changed_parameters(self, stream):
+        """nn.Parameters updated by a torch optimizer -> library masters (device copies)."""
+        seen = getattr(self, "_pushed", None)
+        if seen is None:
+            seen = self._pushed = {}
+        dirty = False
+        for name, prm in self.named_parameters():
+            key = (prm.data_ptr(), prm._version)
+            if seen.get(name) != key:
+                if name in seen:  # first sight = just uploaded through set_param / train_begin
+                    t = prm.detach().to(torch.float32).contiguous()
+                    check(lib().dh_resnet18_train_tensor(self._handle, name.encode(), 0, t.data_ptr(), t.numel(), 1,
+                                                         stream), f"push {name}")
+                    dirty = True
+                seen[name] = key
+        if dirty:
+            check(lib().dh_resnet18_train_repack(self._handle, stream), "dh_resnet18_train_repack")
+
+    def _native_forward_train(self, x):
+        n, p = int(x.shape[0]), int(x.shape[2])
+        st = self._stream(x.device)
+        if self._handle is None or getattr(self, "_train_shape", None) is None:
+            h = self._ensure_handle()   # uploads the current parameters once; later steps push deltas on-device
+            self._pushed = None
+        else:
+            h = self._handle
+        check(lib().dh_resnet18_train_begin(h, n, p, st), "dh_resnet18_train_begin")
+        self._train_shape = (n, p)
+        self._push_changed_parameters(st)
+        out = torch.empty((n, self.n_classes), dtype=torch.float32, device=x.device)
+        check(lib().dh_resnet18_forward_train(h, x.data_ptr(), n, p, out.data_ptr(), st), "dh_resnet18_forward_train")
+        for name, buf in self.named_buffers():  # running statistics back into the module
+            if name.endswith("num_batches_tracked"):
+                buf += 1
+            else:
+                check(lib().dh_resnet18_train_tensor(h, name.encode(), 2, buf.data_ptr(), buf.numel(), 0, st), f"pull {name}")
+        return out
+
+    def _native_backward(self, dlogits):
+        h, st = self._handle, self._stream(dlogits.device)
+        check(lib().dh_resnet18_backward(h, dlogits.data_ptr(), st), "dh_resnet18_backward")
+        grads = []
+        for name, prm in self.named_parameters():
+            g = torch.empty_like(prm, dtype=torch.float32)
+            check(lib().dh_resnet18_train_tensor(h, name.encode(), 1, g.data_ptr(), g.numel(), 0, st), f"grad {name}")
+            grads.append(g if prm.requires_grad else None)
+        return grads
+
+    def train_step(self, x, labels, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        """Fused step entirely in HIP: forward, CrossEntropy(mean), backward, Adam.
+        Returns (loss tensor on device, logits).  nn.Parameters are refreshed lazily by
+        `pull_parameters()` / state_dict()."""
+        if not self.training:
+            raise RuntimeError("train_step needs .train() mode")
+        x = x.detach().to(torch.float32).contiguous()
+        labels = labels.to(device=x.device, dtype=torch.int64).contiguous()
+        logits = self._native_forward_train(x)
+        st = self._stream(x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        dl = torch.empty_like(logits)
+        check(lib().dh_ce_loss(logits.data_ptr(), labels.data_ptr(), logits.shape[0], self.n_classes, loss.data_ptr(),
+                               dl.data_ptr(), st), "dh_ce_loss")
+        check(lib().dh_resnet18_backward(self._handle, dl.data_ptr(), st), "dh_resnet18_backward")
+        self._adam_t = getattr(self, "_adam_t", 0) + 1
+        check(lib().dh_resnet18_adam_step(self._handle, lr, betas[0], betas[1], eps, self._adam_t, st), "dh_resnet18_adam_step")
+        self._native_ahead = True
+        return loss, logits
+
+    def pull_parameters(self):
+        """Library masters -> nn.Parameters (after fused train_step calls)."""
+        if getattr(self, "_native_ahead", False):
+            with torch.no_grad():
+                for name, prm in self.named_parameters():
+                    st = self._stream(prm.device)
+                    check(lib().dh_resnet18_train_tensor(self._handle, name.encode(), 0, prm.data_ptr(), prm.numel(), 0, st),
+                          f"pull {name}")
+                    self._pushed[name] = (prm.data_ptr(), prm._version)
+            self._native_ahead = False
+        return self
+
+    def state_dict(self, *args, **kwargs):
+        self.pull_parameters()
+        return super().state_dict(*args, **kwargs)
 
     def forward_tiles(self, slide: torch.Tensor, origins_dev: torch.Tensor, patch: int) -> torch.Tensor:
         """Fused gather + /255 + forward straight from the uint8 slide in HBM."""

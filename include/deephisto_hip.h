@@ -121,6 +121,38 @@ int dh_resnet18_forward_tiles(dh_resnet18* net, const uint8_t* slide_dev, int64_
                               const int32_t* yx_dev, int64_t n, int32_t patch,
                               float* logits_dev, void* stream);
 
+/* ---- a7: training step (float32) -------------------------------------------------------
+ * Replaces, for the same network, models/patch_cls_simple/train.py:168-172:
+ *   outputs = model(inputs); loss = criterion(outputs, labels); loss.backward(); optimizer.step()
+ * with CrossEntropyLoss (mean) at train.py:117 and Adam(lr) at train.py:118 (PyTorch
+ * defaults: betas (0.9, 0.999), eps 1e-8, no weight decay; BatchNorm momentum 0.1, eps 1e-5,
+ * batch statistics, running statistics updated with the unbiased variance).
+ * Training state (master parameters, gradients, Adam moments, running statistics, saved
+ * activations; all in HBM) is created by the first dh_resnet18_forward_train / _train_begin
+ * for a batch shape from the parameters set with dh_resnet18_set_param, and folded back into
+ * the handle (for eval-mode forwards) by dh_resnet18_train_end.
+ *   forward_train : x_dev float32[n][3][P][P] (must stay alive until backward) -> logits
+ *   backward      : dlogits_dev float32[n][n_classes] -> every parameter gradient
+ *   dh_ce_loss    : mean cross entropy of logits vs int64 labels -> *loss_dev, and (optional)
+ *                   dlogits_dev = (softmax - onehot)/n
+ *   adam_step     : one Adam update of all parameters from the current gradients (step >= 1),
+ *                   then re-packs the MFMA weight copies
+ *   train_tensor  : copy one tensor by state_dict name between the library and caller memory
+ *                   (host or device): kind 0 parameter, 1 gradient, 2 running statistic;
+ *                   to_lib != 0 writes into the library (call train_repack after parameters). */
+int dh_resnet18_train_begin(dh_resnet18* net, int64_t n, int32_t patch, void* stream);
+int dh_resnet18_train_end(dh_resnet18* net);
+int dh_resnet18_forward_train(dh_resnet18* net, const float* x_dev, int64_t n, int32_t patch,
+                              float* logits_dev, void* stream);
+int dh_resnet18_backward(dh_resnet18* net, const float* dlogits_dev, void* stream);
+int dh_ce_loss(const float* logits_dev, const int64_t* labels_dev, int64_t n, int32_t n_cls,
+               float* loss_dev, float* dlogits_dev, void* stream);
+int dh_resnet18_adam_step(dh_resnet18* net, float lr, float beta1, float beta2, float eps,
+                          int64_t step, void* stream);
+int dh_resnet18_train_tensor(dh_resnet18* net, const char* name, int32_t kind, void* ptr,
+                             int64_t n_elem, int32_t to_lib, void* stream);
+int dh_resnet18_train_repack(dh_resnet18* net, void* stream);
+
 /* ---- debug / test hooks (not part of the drop-in boundary) ---------------------
  * dh_debug_conv_bn_act: one conv (ks in {1,3}, pad ks/2) + per-channel scale/shift
  * (+ residual) (+ ReLU) on NHWC data of `dtype`; weights are float32

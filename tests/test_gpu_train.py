@@ -1,0 +1,136 @@
+"""GPU parity, row a7: HIP training step (forward with batch-stat BN, backward, Adam) vs the
+torch-CPU oracle (oracle/resnet18.py, "parity unpinned" against torchvision).
+
+Tolerances (float32 compute, stated per SURVEY section 8d): logits <= 1e-4 abs; loss <= 1e-4
+after step 1 and <= 1e-3 after 3 steps; gradients <= 2e-3 of the tensor's max |grad| (wgrad
+sums over up to 10^5 pixels in a different order, with float atomics)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import resnet18 as oracle_net
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(built_lib):
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _pair(dev, seed):
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    ref = oracle_net.seeded_model(seed, 5, perturb_bn=True)
+    m = get_model(5, "f32")
+    m.load_state_dict(ref.state_dict())
+    return ref.train(), m.to(dev).train()
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize("B,P", [(8, 64), (4, 128)])
+def test_forward_backward_matches_oracle(dev, B, P):
+    ref, m = _pair(dev, 11)
+    g = torch.Generator().manual_seed(B * P)
+    x = torch.rand(B, 3, P, P, generator=g)
+    y = torch.randint(0, 5, (B,), generator=g)
+    out_ref = ref(x)
+    loss_ref = F.cross_entropy(out_ref, y)
+    loss_ref.backward()
+    out = m(x.to(dev))
+    loss = F.cross_entropy(out, y.to(dev))
+    loss.backward()
+    assert float((out.detach().cpu() - out_ref.detach()).abs().max()) <= 1e-4
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4
+    # running statistics (momentum 0.1, unbiased variance) and the batch counter
+    sd, sr = m.state_dict(), ref.state_dict()
+    for k in sr:
+        if "running" in k:
+            assert _rel(sd[k].cpu(), sr[k]) <= 1e-5, k
+        if "tracked" in k:
+            assert int(sd[k]) == int(sr[k]) == 1
+    # gradients, from the head down (localises a failing kernel)
+    ref_g = {k: p.grad for k, p in ref.named_parameters()}
+    worst = {}
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        worst[k] = _rel(p.grad.cpu(), ref_g[k])
+    order = ["fc.bias", "fc.weight", "layer4.1.bn2.bias", "layer4.1.bn2.weight", "layer4.1.conv2.weight",
+             "layer4.1.bn1.weight", "layer4.1.conv1.weight", "layer4.0.conv2.weight", "layer4.0.downsample.0.weight",
+             "layer4.0.conv1.weight", "layer3.1.conv2.weight", "layer2.0.conv1.weight", "layer1.0.conv1.weight",
+             "bn1.weight", "conv1.weight"]
+    for k in order:
+        assert worst[k] <= 2e-3, f"{k}: relative grad error {worst[k]:.3e}"
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, bad
+
+
+def test_three_adam_steps_torch_optimizer(dev):
+    """The reference's loop shape: criterion + loss.backward() + torch.optim.Adam.step()."""
+    ref, m = _pair(dev, 5)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(3)
+    for step in range(3):
+        x = torch.rand(8, 3, 64, 64, generator=g)
+        y = torch.randint(0, 5, (8,), generator=g)
+        l_ref, _ = oracle_net.train_step(ref, opt_ref, x, y)
+        opt.zero_grad()
+        out = m(x.to(dev))
+        loss = F.cross_entropy(out, y.to(dev))
+        loss.backward()
+        opt.step()
+        assert abs(float(loss) - l_ref) <= (1e-4 if step == 0 else 1e-3), (step, float(loss), l_ref)
+    # Adam's update is ~lr*sign(g) while v is young: an element whose gradient is within rounding of
+    # zero may move the other way, so single elements can differ by up to 2*lr per step; the bulk must agree.
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        d = (p.detach().cpu() - q.detach()).abs()
+        assert float(d.max()) <= 6e-4 and float(d.mean()) <= 2e-5, (k, float(d.max()), float(d.mean()))
+
+
+def test_fused_train_step_and_eval_roundtrip(dev):
+    """HIP CrossEntropy + fused Adam (model.train_step), then eval-mode inference and a
+    state_dict round trip through the oracle."""
+    ref, m = _pair(dev, 9)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(4)
+    for step in range(3):
+        x = torch.rand(8, 3, 64, 64, generator=g)
+        y = torch.randint(0, 5, (8,), generator=g)
+        l_ref, _ = oracle_net.train_step(ref, opt_ref, x, y)
+        loss, _ = m.train_step(x.to(dev), y.to(dev), lr=1e-4)
+        assert abs(float(loss) - l_ref) <= (1e-4 if step == 0 else 1e-3), (step, float(loss), l_ref)
+    sd = m.state_dict()
+    for k, v in ref.state_dict().items():
+        if "tracked" in k:
+            assert int(sd[k]) == int(v)
+        elif "running" in k:
+            assert _rel(sd[k].cpu(), v) <= 1e-4, k
+        else:
+            d = (sd[k].cpu() - v).abs()
+            assert float(d.max()) <= 6e-4 and float(d.mean()) <= 2e-5, (k, float(d.max()), float(d.mean()))
+    xe = torch.rand(4, 3, 96, 96, generator=g)
+    with torch.no_grad():
+        want = ref.eval()(xe)
+    got = m.eval()(xe.to(dev))
+    assert float((got.cpu() - want).abs().max()) <= 5e-4
+
+
+def test_ce_loss_kernel(dev):
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(0)
+    logits = (torch.randn(37, 5, generator=g) * 3).to(dev)
+    y = torch.randint(0, 5, (37,), generator=g).to(dev)
+    loss = torch.empty((), device=dev)
+    dl = torch.empty_like(logits)
+    check(lib().dh_ce_loss(logits.data_ptr(), y.data_ptr(), 37, 5, loss.data_ptr(), dl.data_ptr(), None), "ce")
+    torch.cuda.synchronize()
+    lr = logits.detach().cpu().requires_grad_(True)
+    want = F.cross_entropy(lr, y.cpu())
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 1e-5
+    assert float((dl.cpu() - lr.grad).abs().max()) <= 1e-6
