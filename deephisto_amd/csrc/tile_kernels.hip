@@ -282,6 +282,50 @@ extern "C" int dh_tile_gather(const uint8_t* slide, int64_t h, int64_t w, const 
   return DH_OK;
 }
 
+// Gather with the batch-level flips of the training pipeline (train.py:71-81 applies
+// RandomHorizontalFlip / RandomVerticalFlip to the whole [B,C,H,W] batch: one coin per batch).
+template <bool BF16, bool NCHW>
+__global__ __launch_bounds__(256) void gather_aug_kernel(const uint8_t* __restrict__ slide, int64_t row_bytes,
+                                                         const int32_t* __restrict__ yx, int P, int flip_h, int flip_v,
+                                                         void* __restrict__ outv) {
+  const int t = blockIdx.y;
+  const int y0 = yx[2 * t], x0 = yx[2 * t + 1];
+  const int64_t per_tile = (int64_t)P * P * 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_tile; i += (int64_t)gridDim.x * blockDim.x) {
+    // i enumerates OUTPUT elements in output order
+    int r, px, c;
+    if (NCHW) { c = (int)(i / ((int64_t)P * P)); const int rem = (int)(i - (int64_t)c * P * P); r = rem / P; px = rem - r * P; }
+    else { r = (int)(i / (3 * P)); const int rem = (int)(i - (int64_t)r * 3 * P); px = rem / 3; c = rem - 3 * px; }
+    const int sr = flip_v ? P - 1 - r : r, sx = flip_h ? P - 1 - px : px;
+    const float f = div255(slide[(int64_t)(y0 + sr) * row_bytes + (int64_t)(x0 + sx) * 3 + c]);
+    const int64_t o = (int64_t)t * per_tile + i;
+    if constexpr (BF16) static_cast<uint16_t*>(outv)[o] = (uint16_t)f32_to_bf16_bits(f);
+    else static_cast<float*>(outv)[o] = f;
+  }
+}
+
+extern "C" int dh_tile_gather_aug(const uint8_t* slide, int64_t h, int64_t w, const int32_t* yx_dev, int64_t n, int32_t P,
+                                  int32_t layout, int32_t dtype, int32_t flip_h, int32_t flip_v, void* out, void* stream) {
+  DH_REQUIRE(n >= 0 && n <= 65535, "tile gather aug: n=%lld out of range", (long long)n);
+  if (n == 0) return DH_OK;
+  DH_REQUIRE(slide && yx_dev && out && P > 0 && h >= P && w >= P, "tile gather aug: bad arguments");
+  DH_REQUIRE((layout == DH_LAYOUT_NHWC || layout == DH_LAYOUT_NCHW) && (dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16),
+             "tile gather aug: bad layout/dtype");
+  hipStream_t st = dh::as_stream(stream);
+  const int64_t per_tile = (int64_t)P * P * 3;
+  dim3 grid((unsigned)std::min<int64_t>((per_tile + 255) / 256, 1024), (unsigned)n), block(256);
+  const int64_t rb = w * 3;
+  if (layout == DH_LAYOUT_NCHW) {
+    if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL((gather_aug_kernel<false, true>), grid, block, 0, st, slide, rb, yx_dev, P, flip_h, flip_v, out);
+    else hipLaunchKernelGGL((gather_aug_kernel<true, true>), grid, block, 0, st, slide, rb, yx_dev, P, flip_h, flip_v, out);
+  } else {
+    if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL((gather_aug_kernel<false, false>), grid, block, 0, st, slide, rb, yx_dev, P, flip_h, flip_v, out);
+    else hipLaunchKernelGGL((gather_aug_kernel<true, false>), grid, block, 0, st, slide, rb, yx_dev, P, flip_h, flip_v, out);
+  }
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
 __global__ void coords_kernel(const int32_t* __restrict__ yx, int64_t n2, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n2) out[i] = (float)yx[i];

@@ -247,6 +247,8 @@ class ResNet18HIP(nn.Module):
                           f"pull {name}")
                     self._pushed[name] = (prm.data_ptr(), prm._version)
             self._native_ahead = False
+            self._synced = None  # the raw copies above do not bump torch's version counters: force the
+            #                      eval-mode copy of the parameters to be rebuilt on its next use
         return self
 
     def state_dict(self, *args, **kwargs):

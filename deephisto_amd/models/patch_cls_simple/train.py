@@ -1,0 +1,122 @@
+"""`train(cfg)` -- drop-in for models/patch_cls_simple/train.py:59-301 (the training entry point).
+
+Same config schema (config.yaml), same loop structure: per epoch 200 training steps
+(train.py:142), `val_steps` validation steps drawn from the SAME sampler with the same
+augmentations (train.py:198-204), `ReduceLROnPlateau(min, 0.1, patience 5)` on the validation
+loss (train.py:120-122, 240), best-validation-accuracy checkpoint `out_dir/best_model.pth`
+holding `model.state_dict()` (train.py:244-249).
+
+What moved to the GPU: the step itself (forward, CrossEntropy, backward, Adam: HIP kernels,
+`ResNet18HIP.train_step`), batch assembly (gather + /255 + NCHW + batch-level flips in
+`dh_tile_gather_aug`), and the running loss / accuracy sums (accumulated on the device, read
+once per epoch instead of four host syncs per step, train.py:174-180).
+
+Not reproduced: the ImageFolder test loop and the JPEG plots (train.py:253-301; disk I/O and
+matplotlib, out of scope), and the polygon annotations (shapely): the data source is any
+object with `device_batches(batch_size, n_batches)` such as `RectRegionRndSampler`; when
+`cfg["dataset"]["folder"]` does not exist a closed-form synthetic slide with rectangular
+regions is used (BASELINE configs[1]).
+"""
+from __future__ import annotations
+
+import argparse
+from pathlib import Path
+
+import torch
+
+from . import utils
+from .model import get_model
+from ...patch_samplers.region_samplers import RectRegionRndSampler, synthetic_regions
+
+
+def _synthetic_sampler(cfg, device):
+    from ... import tiles
+
+    side = int(cfg.get("runtime", {}).get("synthetic_slide", 8192))
+    slide = tiles.synth_slide(side, side, 0, device)
+    regions = synthetic_regions(side, side, cfg["model"]["n_classes"], seed=0)
+    return RectRegionRndSampler(slide, regions, layer=cfg["dataset"]["layer"], patch_size=cfg["dataset"]["patch_size"],
+                                patches_from_one_region=cfg["dataset"]["patches_from_one_region"], device=device)
+
+
+class _PlateauLR:
+    """ReduceLROnPlateau(mode="min", factor=0.1, patience=5) (train.py:120-122) for the fused step."""
+
+    def __init__(self, lr, factor=0.1, patience=5, threshold=1e-4):
+        self.lr, self.factor, self.patience, self.threshold = lr, factor, patience, threshold
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric):
+        if metric < self.best * (1 - self.threshold):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+            if self.bad > self.patience:
+                self.lr, self.bad = self.lr * self.factor, 0
+        return self.lr
+
+
+def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
+    device = utils.get_device()
+    log(f"Using device: {device}")
+    if device.type != "cuda":
+        raise RuntimeError("deephisto_amd trains on the GPU only (HIP kernels); no CPU fallback")
+    Path(cfg["training"]["save_dir"]).mkdir(parents=True, exist_ok=True)
+    out_dir = Path(cfg["training"]["out_dir"])
+    out_dir.mkdir(parents=True, exist_ok=True)
+
+    if sampler is None:
+        folder = Path(cfg["dataset"]["folder"])
+        if folder.exists():
+            raise NotImplementedError("reading annotated .psi datasets needs psimage + polygon geometry "
+                                      "(SURVEY section 8f row 2); pass a sampler or use the synthetic source")
+        sampler = _synthetic_sampler(cfg, device)
+
+    bs = cfg["training"]["batch_size"]
+    model = get_model(cfg["model"]["n_classes"], cfg.get("runtime", {}).get("compute_dtype", "f32")).to(device)
+    sched = _PlateauLR(cfg["training"]["lr"])
+    history = {"train_loss": [], "train_acc": [], "val_loss": [], "val_acc": [], "lr": []}
+    best_val_acc = 0.0
+    n_epochs = epochs if epochs is not None else cfg["training"]["n_epochs"]
+
+    for epoch in range(n_epochs):
+        model.train()
+        loss_sum = torch.zeros((), device=device)
+        correct = torch.zeros((), device=device, dtype=torch.int64)
+        total = 0
+        for x, labels, _ in sampler.device_batches(bs, steps_per_epoch, flips=True):
+            loss, logits = model.train_step(x, labels, lr=sched.lr)   # HIP: fwd + CE + bwd + Adam
+            loss_sum += loss
+            correct += (logits.argmax(1) == labels).sum()
+            total += labels.numel()
+        train_loss, train_acc = float(loss_sum) / steps_per_epoch, int(correct) / total
+        log(f"Epoch {epoch + 1}/{n_epochs}  Train Loss: {train_loss:.4f}, Train Acc: {train_acc:.4f}")
+
+        # validation: same sampler, same augmentations, eval-mode BN, no update (train.py:190-236)
+        model.eval()
+        val_steps = cfg["training"]["val_steps"]
+        vloss = torch.zeros((), device=device)
+        vcorrect, vtotal = torch.zeros((), device=device, dtype=torch.int64), 0
+        for x, labels, _ in sampler.device_batches(bs, val_steps, flips=True):
+            logits = model(x)
+            vloss += torch.nn.functional.cross_entropy(logits, labels)
+            vcorrect += (logits.argmax(1) == labels).sum()
+            vtotal += labels.numel()
+        val_loss, val_acc = float(vloss) / val_steps, int(vcorrect) / vtotal
+        log(f"Val Loss: {val_loss:.4f}, Val Acc: {val_acc:.4f}")
+        lr = sched.step(val_loss)
+        log(f"Current Learning Rate: {lr:.6f}")
+        if val_acc > best_val_acc:
+            best_val_acc = val_acc
+            torch.save(model.state_dict(), out_dir / "best_model.pth")
+        for k, v in zip(history, (train_loss, train_acc, val_loss, val_acc, lr)):
+            history[k].append(v)
+    return model, history
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", default=str(Path(__file__).with_name("config.yaml")))
+    parser.add_argument("--epochs", type=int, default=None)
+    args = parser.parse_args()
+    train(utils.load_config(Path(args.config)), epochs=args.epochs)

@@ -79,6 +79,21 @@ def gather_tiles(slide: torch.Tensor, origins, patch: int, layout: int = DH_LAYO
     return out
 
 
+def gather_tiles_aug(slide: torch.Tensor, origins_dev: torch.Tensor, patch: int, layout: int = DH_LAYOUT_NCHW,
+                     dtype=torch.float32, flip_h: bool = False, flip_v: bool = False) -> torch.Tensor:
+    """gather_tiles with the training pipeline's batch-level flips fused in (dh_tile_gather_aug)."""
+    _require_cuda(slide, "slide")
+    _require_cuda(origins_dev, "origins")
+    n = int(origins_dev.shape[0])
+    code = dtype_code(dtype)
+    shape = (n, 3, patch, patch) if layout == DH_LAYOUT_NCHW else (n, patch, patch, 3)
+    out = torch.empty(shape, dtype=_TORCH_DTYPE[code], device=slide.device)
+    check(lib().dh_tile_gather_aug(slide.data_ptr(), int(slide.shape[0]), int(slide.shape[1]), origins_dev.data_ptr(), n,
+                                   patch, layout, code, int(flip_h), int(flip_v), out.data_ptr(), _stream(slide.device)),
+          "dh_tile_gather_aug")
+    return out
+
+
 def tile_coords(origins_dev: torch.Tensor) -> torch.Tensor:
     """float32[n, 2] (pos_y, pos_x) from int32 device origins (full_samplers.py:444-451)."""
     _require_cuda(origins_dev, "origins")

@@ -73,6 +73,15 @@ int dh_tile_gather(const uint8_t* slide_dev, int64_t h, int64_t w, const int32_t
                    const int32_t* yx_host_check, int64_t n, int32_t patch, int32_t layout,
                    int32_t dtype, void* out_dev, void* stream);
 
+/* Same gather with the batch-level augmentation of the training pipeline fused in
+ * (models/patch_cls_simple/train.py:71-81: permute to NCHW, then RandomHorizontalFlip /
+ * RandomVerticalFlip applied to the whole batch, i.e. one coin per batch): flip_h mirrors
+ * columns, flip_v mirrors rows of every tile.  Feeds the a9 output contract
+ * (patch_samplers/region_samplers.py:616-621, 729-738). */
+int dh_tile_gather_aug(const uint8_t* slide_dev, int64_t h, int64_t w, const int32_t* yx_dev,
+                       int64_t n, int32_t patch, int32_t layout, int32_t dtype, int32_t flip_h,
+                       int32_t flip_v, void* out_dev, void* stream);
+
 /* coords tensor of generator_torch (full_samplers.py:444-451): float32[n][2]. */
 int dh_tile_coords_f32(const int32_t* yx_dev, int64_t n, float* out_dev, void* stream);
 
