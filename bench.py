@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=10,
+                    help="extra leg: time this many fused training steps (BASELINE configs[1]); 0 = skip")
     return ap.parse_args()
 
 
@@ -98,6 +100,35 @@ def cpu_baseline(args, budget_s: float) -> dict:
             "sample": f"first {len(o)} tiles ({len(used)} batches of {args.batch}) of a {side}x{side} "
                       f"closed-form slide, patch {args.patch} stride {args.stride}, torch-CPU fp32 "
                       f"ResNet-18 eager, {threads} threads, {dt:.1f} s"}
+
+
+def train_leg(dev, steps: int) -> dict:
+    """BASELINE configs[1]: models.patch_cls_simple.train step on synthetic annotated regions,
+    1 GPU, fp32: batch 64 x 3 x 224 x 224 (config.yaml), HIP forward + CE + backward + Adam."""
+    from deephisto_amd import tiles
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    from deephisto_amd.patch_samplers.region_samplers import RectRegionRndSampler, synthetic_regions
+
+    side, B, P = 8192, 64, 224
+    slide = tiles.synth_slide(side, side, 1, dev)
+    smp = RectRegionRndSampler(slide, synthetic_regions(side, side, 5, seed=0), layer=1, patch_size=P, seed=0, device=dev)
+    torch.manual_seed(0)
+    model = get_model(5, "f32").to(dev).train()
+    it = smp.device_batches(B, steps + 2, flips=True)
+    for _ in range(2):
+        x, y, _c = next(it)
+        model.train_step(x, y, lr=1e-4)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for x, y, _c in it:
+        loss, _ = model.train_step(x, y, lr=1e-4)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"steps_per_s": steps / dt, "samples_per_s": steps * B / dt, "ms_per_step": 1e3 * dt / steps,
+            "config": {"workload": "BASELINE configs[1]: train step (fwd + CrossEntropy + bwd + Adam, HIP) on synthetic "
+                                   "annotated regions, data assembly (gather + /255 + flips) included",
+                       "batch": B, "patch": P, "dtype": "f32", "steps": steps, "last_loss": float(loss)},
+            "model_tflops": steps * B * 3 * 3.6271e9 / dt / 1e12}
 
 
 def main():
@@ -185,6 +216,10 @@ def main():
                          "avg_launch_us": 1e3 * k_ms.value / max(1, k_n.value),
                          "flops_per_launch": k_flops.value / max(1, k_n.value)},
         }
+        if args.train_steps > 0 and world == 1:
+            del slide, smp
+            torch.cuda.empty_cache()
+            out["train"] = train_leg(dev, args.train_steps)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         elif world > 1:

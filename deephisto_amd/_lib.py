@@ -49,6 +49,7 @@ SIGNATURES = {
     "dh_resnet18_adam_step": (C.c_int, [_p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
     "dh_resnet18_train_tensor": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _i32, _p]),
     "dh_resnet18_train_repack": (C.c_int, [_p, _p]),
+    "dh_resnet18_train_flat": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),
     "dh_debug_conv_bn_act": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i32] * 9 + [_p]),
     "dh_debug_stem_out": (C.c_int, [_p, _i64, _i32, _p, _p]),
     "dh_debug_stamps": (C.c_int, [_i32, _p]),

@@ -35,6 +35,26 @@ class _BlockParams(nn.Module):
                                             nn.BatchNorm2d(cout))
 
 
+class _DevView:
+    """float32 device memory owned by the native library, exposed through the CUDA array interface."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place mean of `flat` over the ranks of `group` (data-parallel gradient exchange).
+    One collective over the whole 44.7 MB gradient arena: RCCL all-reduce on GPUs
+    (backend "nccl"); identical code path on gloo in the CPU tests."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+    return flat
+
+
 class _TrainForward(torch.autograd.Function):
     """logits = model(x) in training mode; backward runs the HIP backward kernels and hands
     every parameter its gradient (so `loss.backward(); optimizer.step()` of
@@ -217,8 +237,17 @@ class ResNet18HIP(nn.Module):
             grads.append(g if prm.requires_grad else None)
         return grads
 
-    def train_step(self, x, labels, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def flat_gradients(self, device) -> torch.Tensor:
+        """The library's whole gradient arena as one float32 tensor view (no copy)."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        check(lib().dh_resnet18_train_flat(self._handle, 1, C.byref(ptr), C.byref(n)), "dh_resnet18_train_flat")
+        return torch.as_tensor(_DevView(ptr.value, n.value), device=device)
+
+    def train_step(self, x, labels, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None):
         """Fused step entirely in HIP: forward, CrossEntropy(mean), backward, Adam.
+        Under torch.distributed (one process per GPU) the gradients are averaged over `group`
+        with one all-reduce of the flat gradient arena between backward and Adam (DDP
+        semantics: per-rank batch statistics, replicas stay identical).
         Returns (loss tensor on device, logits).  nn.Parameters are refreshed lazily by
         `pull_parameters()` / state_dict()."""
         if not self.training:
@@ -232,6 +261,9 @@ class ResNet18HIP(nn.Module):
         check(lib().dh_ce_loss(logits.data_ptr(), labels.data_ptr(), logits.shape[0], self.n_classes, loss.data_ptr(),
                                dl.data_ptr(), st), "dh_ce_loss")
         check(lib().dh_resnet18_backward(self._handle, dl.data_ptr(), st), "dh_resnet18_backward")
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            allreduce_mean_(self.flat_gradients(x.device), group)
         self._adam_t = getattr(self, "_adam_t", 0) + 1
         check(lib().dh_resnet18_adam_step(self._handle, lr, betas[0], betas[1], eps, self._adam_t, st), "dh_resnet18_adam_step")
         self._native_ahead = True

@@ -161,6 +161,9 @@ int dh_resnet18_adam_step(dh_resnet18* net, float lr, float beta1, float beta2, 
 int dh_resnet18_train_tensor(dh_resnet18* net, const char* name, int32_t kind, void* ptr,
                              int64_t n_elem, int32_t to_lib, void* stream);
 int dh_resnet18_train_repack(dh_resnet18* net, void* stream);
+/* Device pointer + element count of a whole arena (kind as above): data-parallel training
+ * all-reduces the gradient arena in place (RCCL) between backward and adam_step. */
+int dh_resnet18_train_flat(dh_resnet18* net, int32_t kind, void** ptr_out, int64_t* n_out);
 
 /* ---- debug / test hooks (not part of the drop-in boundary) ---------------------
  * dh_debug_conv_bn_act: one conv (ks in {1,3}, pad ks/2) + per-channel scale/shift
