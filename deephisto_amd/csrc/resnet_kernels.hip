@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvParams p) {
 }
 
 #include "conv3x3.inc"
+#include "stem_pool.inc"
 
 // ---------------------------------------------------------------------------
 // Stem: conv 7x7 / stride 2 / pad 3, 3 -> 64, + BN + ReLU, output NHWC.
@@ -613,6 +614,9 @@ void pack_stem_weights(const float* w, int esz, std::vector<uint8_t>& out) {
 // Optional in-library timing of the dominant kernel (3x3 stride-1 conv): HIP events on
 // the launch stream around sampled launches, summed by dh_profile_stop (bench.py's
 // `roofline.achieved`).  Off by default; costs nothing when off.
+bool g_stamps_on = false;
+unsigned long long* g_stamps_dev = nullptr;
+
 struct Profiler {
   bool on = false;
   int every = 1, counter = 0;
@@ -639,9 +643,63 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
   return DH_OK;
 }
 
-bool g_stamps_on = false;
-unsigned long long* g_stamps_dev = nullptr;
 void* g_zero_page = nullptr;  // 1 KiB of zeros: DMA source of padding pixels
+
+// Host-built lookup tables of the conv3x3 kernel, cached per layer shape for the life of the
+// process (a handful of shapes; a few KiB each): per-thread geometry and per-tile decode.
+struct Conv3Tables { int* lane = nullptr; int4* tile = nullptr; };
+std::map<std::vector<int>, Conv3Tables> g_conv3_tables;
+
+template <int STRIDE, int NT, int WAVES, int ESZ>
+int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out) {
+  constexpr int MAXJ = (STRIDE == 2) ? 10 : (NT == 2 ? 6 : 4);
+  const std::vector<int> key = {STRIDE, NT, WAVES, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi, p.Cin,
+                                p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr};
+  auto it = g_conv3_tables.find(key);
+  if (it != g_conv3_tables.end()) { *out = it->second; return DH_OK; }
+  const int threads = WAVES * 64, stride = 2 * NT + 2 * MAXJ;
+  std::vector<int> lane((size_t)threads * stride);
+  for (int tid = 0; tid < threads; ++tid) {
+    const int l = tid & 63, wave = tid >> 6;
+    int* row = &lane[(size_t)tid * stride];
+    for (int nt = 0; nt < NT; ++nt) {
+      const int pidx = (wave * NT + nt) * 32 + (l & 31);
+      const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
+      const int ty = rem / p.TW, tx = rem % p.TW;
+      row[2 * nt] = ty | (tx << 8) | (img << 16);
+      row[2 * nt + 1] = (img * p.HR + ty * STRIDE) * p.HP + tx;
+    }
+    // window DMA: instruction i = wave + WAVES*j fills LDS pixels 16i..16i+15; lane l fills LDS slot (l&3)
+    // of pixel 16i + l/4 with GLOBAL slot (l&3) ^ swizzle(pixel)
+    for (int j = 0; j < MAXJ; ++j) {
+      const int i = wave + WAVES * j;
+      const int px = i * 16 + (l >> 2);
+      const int img = px / (p.HR * p.HP), r = px % (p.HR * p.HP);
+      const int hy = r / p.HP, c = r % p.HP;
+      int hx = c;
+      if (STRIDE == 2) hx = 2 * (c % p.HPH) + c / p.HPH;
+      const bool live = i < p.n_win_instr && img < p.IMGS && hx < p.HC;
+      const int g = (l & 3) ^ ((px >> 2) & 3);
+      row[2 * NT + 2 * j] = ((img * p.Hi + hy - 1) * p.Wi + hx - 1) * p.Cin * ESZ + g * 16;
+      row[2 * NT + 2 * j + 1] = (hy & 0xFF) | ((hx & 0xFF) << 8) | ((img & 0xFF) << 16) | ((live ? 1 : 0) << 24);
+    }
+  }
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  std::vector<int4> tile((size_t)p.ntiles);
+  for (int T_ = 0; T_ < p.ntiles; ++T_) {
+    const int pt = T_ / ncb, t = pt % tiles_per_img;
+    tile[T_] = make_int4(T_ % ncb, (pt / tiles_per_img) * p.IMGS, (t / p.tiles_x) * p.TH, (t % p.tiles_x) * p.TW);
+  }
+  Conv3Tables tb;
+  DH_HIP(hipMalloc((void**)&tb.lane, lane.size() * sizeof(int)));
+  DH_HIP(hipMalloc((void**)&tb.tile, tile.size() * sizeof(int4)));
+  DH_HIP(hipMemcpy(tb.lane, lane.data(), lane.size() * sizeof(int), hipMemcpyHostToDevice));
+  DH_HIP(hipMemcpy(tb.tile, tile.data(), tile.size() * sizeof(int4), hipMemcpyHostToDevice));
+  g_conv3_tables[key] = tb;
+  *out = tb;
+  (void)groups_img;
+  return DH_OK;
+}
 
 template <typename T, int STRIDE, int NT, int WAVES>
 int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
@@ -658,6 +716,10 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   p.ntiles = groups * (L.cout / 64);
   const int grid = std::min(256, p.ntiles);  // persistent: one workgroup per CU
   p.iters = (p.ntiles + grid - 1) / grid;
+  Conv3Tables tb;
+  int rc = conv3_tables<STRIDE, NT, WAVES, (int)sizeof(T)>(p, L.cout / 64, groups, &tb);
+  if (rc) return rc;
+  p.lane_tab = tb.lane; p.tile_tab = tb.tile;
   static bool attr_set = false;
   if (!attr_set) {
     DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false>),
@@ -749,7 +811,7 @@ int run_conv(const ConvLayer& L, const void* in, const void* res, void* out, int
 }
 
 template <typename T>
-int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t slide_w,
+int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t slide_h, int64_t slide_w,
                  const int32_t* yx, int64_t n64, int P, float* logits, hipStream_t st) {
   const int B = (int)n64;
   const int esz = (int)sizeof(T);
@@ -771,6 +833,36 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
   void* bufB = base + al(stem_bytes) + al(act_bytes);
   void* bufC = base + al(stem_bytes) + 2 * al(act_bytes);
 
+  if constexpr (sizeof(T) == 2) {
+    // bf16: fused stem + BN + ReLU + maxpool (persistent, weights resident in LDS), straight into bufA
+    StemPoolParams sp;
+    sp.x_nchw = x; sp.slide = slide; sp.yx = yx; sp.row_bytes = slide_w * 3; sp.slide_bytes = slide_h * slide_w * 3;
+    sp.w = net->convs[0].w_dev; sp.scale = net->convs[0].scale_dev; sp.shift = net->convs[0].shift_dev; sp.out = bufA;
+    sp.B = B; sp.P = P; sp.Hc = H1; sp.Wc = H1; sp.Hp = H2; sp.Wp = H2;
+    sp.tiles_y = (H2 + SP_PR - 1) / SP_PR; sp.tiles_x = (H2 + SP_PC - 1) / SP_PC;
+    sp.ntiles = B * sp.tiles_y * sp.tiles_x;
+    const int grid = std::min(256, sp.ntiles);
+    sp.iters = (sp.ntiles + grid - 1) / grid;
+    static bool a = false;
+    if (!a) {
+      DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
+      DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
+      DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
+      a = true;
+    }
+    sp.stamps = nullptr;
+    if (g_stamps_on && slide) {
+      if (!g_stamps_dev) {
+        DH_HIP(hipMalloc((void**)&g_stamps_dev, 64 * sizeof(unsigned long long)));
+        DH_HIP(hipMemset(g_stamps_dev, 0, 64 * sizeof(unsigned long long)));
+      }
+      sp.stamps = g_stamps_dev + 8 * 7;
+    }
+    if (slide && sp.stamps) hipLaunchKernelGGL((stem_pool_kernel<true, true>), dim3(grid), dim3(512), SP_LDS, st, sp);
+    else if (slide) hipLaunchKernelGGL((stem_pool_kernel<true, false>), dim3(grid), dim3(512), SP_LDS, st, sp);
+    else hipLaunchKernelGGL((stem_pool_kernel<false, false>), dim3(grid), dim3(512), SP_LDS, st, sp);
+    DH_LAUNCH_CHECK();
+  } else {
   // stem
   {
     StemParams sp;
@@ -799,6 +891,7 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
     hipLaunchKernelGGL((maxpool_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(S),
                        static_cast<T*>(bufA), B, H1, H1, 64, H2, H2);
     DH_LAUNCH_CHECK();
+  }
   }
   // residual stages: X lives in bufA; T in bufB; downsample in bufC
   int H = H2, W = H2;
@@ -936,8 +1029,8 @@ extern "C" int dh_resnet18_forward(dh_resnet18* net, const float* x, int64_t n, 
   DH_REQUIRE(x != nullptr, "resnet18 forward: null input");
   hipStream_t st = dh::as_stream(stream);
   return net->dtype == DH_DTYPE_F32
-             ? forward_impl<float>(net, x, nullptr, 0, nullptr, n, P, logits, st)
-             : forward_impl<__bf16>(net, x, nullptr, 0, nullptr, n, P, logits, st);
+             ? forward_impl<float>(net, x, nullptr, 0, 0, nullptr, n, P, logits, st)
+             : forward_impl<__bf16>(net, x, nullptr, 0, 0, nullptr, n, P, logits, st);
 }
 
 extern "C" int dh_resnet18_forward_tiles(dh_resnet18* net, const uint8_t* slide, int64_t h, int64_t w,
@@ -951,8 +1044,8 @@ extern "C" int dh_resnet18_forward_tiles(dh_resnet18* net, const uint8_t* slide,
              (long long)h, (long long)w);
   hipStream_t st = dh::as_stream(stream);
   return net->dtype == DH_DTYPE_F32
-             ? forward_impl<float>(net, nullptr, slide, w, yx, n, P, logits, st)
-             : forward_impl<__bf16>(net, nullptr, slide, w, yx, n, P, logits, st);
+             ? forward_impl<float>(net, nullptr, slide, h, w, yx, n, P, logits, st)
+             : forward_impl<__bf16>(net, nullptr, slide, h, w, yx, n, P, logits, st);
 }
 
 // ---------------------------------------------------------------------------

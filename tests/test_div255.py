@@ -27,3 +27,13 @@ def test_div255_sequence_is_correctly_rounded():
         got = fma32(e, r, q)
         want = Fraction(float(np.float32(k) / np.float32(255)))
         assert got == want, k
+
+
+def test_bf16_single_multiply_equals_division():
+    """The fused stem kernel normalises with ONE multiply when the target is bf16:
+    bf16(k * float32(1/255)) must equal bf16(float32(k) / 255) for every byte value."""
+    import torch
+    k = np.arange(256, dtype=np.float32)
+    a = torch.from_numpy(k * np.float32(1.0 / 255.0)).to(torch.bfloat16)
+    b = torch.from_numpy(k / np.float32(255)).to(torch.bfloat16)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))

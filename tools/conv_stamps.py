@@ -11,18 +11,24 @@ from deephisto_amd.models.patch_cls_simple.model import get_model
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device("cuda:0")
 m = get_model(5, "bf16").to(dev).eval()
-x = torch.rand(B, 3, 256, 256, device=dev)
-m(x); torch.cuda.synchronize()
+from deephisto_amd import tiles
+slide = tiles.synth_slide(4096, 4096, 0, dev)
+o = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+o[:, 0] = torch.arange(B, device=dev, dtype=torch.int32) % 15 * 256
+o[:, 1] = torch.arange(B, device=dev, dtype=torch.int32) // 15 * 256
+m.forward_tiles(slide, o, 256); torch.cuda.synchronize()
 check(lib().dh_debug_stamps(1, None), "stamps on")
 for _ in range(3):
-    m(x)
+    m.forward_tiles(slide, o, 256)
 out = np.zeros(64, np.uint64)
 check(lib().dh_debug_stamps(0, out.ctypes.data), "stamps read")
-names = ["s1 cin64", "s1 cin128", "s1 cin256", "s1 cin512", "s2 cin64", "s2 cin128", "s2 cin256"]
-print("row           wgs   cyc/wg   load%  mfma%  bar1%  epil%  ldsw%  bar2%")
+names = ["s1 cin64", "s1 cin128", "s1 cin256", "s1 cin512", "s2 cin64", "s2 cin128", "s2 cin256",
+         "stem+pool (slots: prefetch, mfma, epilogue, barrier, pool, stage+barrier)"]
+print("row           wgs   cyc/wg  cursor%  epil%  mfma%  barr%  prolog% tail%")
 for r, n in enumerate(names):
     v = out[8 * r:8 * r + 8].astype(np.float64)
     if v[6] == 0:
         continue
     tot = v[:6].sum()
-    print(f"{n:12s} {int(v[6]):5d} {tot / v[6]:8.0f}  " + "  ".join(f"{100 * a / tot:5.1f}" for a in v[:6]))
+    ghz = tot / max(v[7], 1) * 0.1   # shader cycles per 100 MHz tick
+    print(f"{n:12s} {int(v[6]):5d} {tot / v[6]:8.0f}  " + "  ".join(f"{100 * a / tot:5.1f}" for a in v[:6]) + f"   clock {ghz:4.2f} GHz")
