@@ -194,6 +194,10 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = (k_flops.value / (k_ms.value * 1e-3)) / 1e12 if k_ms.value > 0 else 0.0
         flop_tile = FLOP_PER_TILE_256 * (args.patch / 256.0) ** 2
+        traffic = None   # HBM bytes per launch of the dominant kernel: from the committed PMC passes (rocprofv3
+        pmc = REPO / "profiles" / "r01_pmc_dominant_kernel.json"   # cannot run inside the timed process)
+        if pmc.exists() and args.micro_batch == 128 and args.dtype == "bf16" and args.patch == 256:
+            traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
         out = {
             "metric": "256x256 patches/sec WSI inference (predict_full_patched)",
             "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,7 +215,7 @@ def main():
             "model_tflops": value * flop_tile / 1e12,
             "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<{args.dtype}, stride 1, NT=2, 8 waves> (layers 1-3, 10 of 20 convs)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": traffic,
                          "launches_timed": int(k_n.value),
                          "avg_launch_us": 1e3 * k_ms.value / max(1, k_n.value),
                          "flops_per_launch": k_flops.value / max(1, k_n.value)},
