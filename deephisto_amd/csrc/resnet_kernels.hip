@@ -701,11 +701,11 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
   return DH_OK;
 }
 
-template <typename T, int STRIDE, int NT, int WAVES>
+template <typename T, int STRIDE, int NT, int WAVES, bool DS = false>
 int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   const int win_bytes = p.IMGS * p.HR * p.HP * CHUNK_BYTES;
-  const size_t buf = (size_t)9 * SLAB_TAP + ((win_bytes + 1023) & ~1023);
-  const size_t lds = 2 * buf + 1024;  // 2-deep ring + [2][scale|shift]
+  const size_t buf = (size_t)(9 + (DS ? 1 : 0)) * SLAB_TAP + ((win_bytes + 1023) & ~1023);
+  const size_t lds = 2 * buf + (DS ? 2048 : 1024);  // 2-deep ring + [2][scale|shift(|ds scale|ds shift)]
   constexpr int MAXJ = (STRIDE == 2) ? 10 : (NT == 2 ? 6 : 4);
   p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
   DH_REQUIRE(p.n_win_instr <= MAXJ * WAVES, "conv3x3: staging window too large for the DMA plan");
@@ -722,22 +722,24 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   p.lane_tab = tb.lane; p.tile_tab = tb.tile;
   static bool attr_set = false;
   if (!attr_set) {
-    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false>),
+    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true>),
+    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true>), dim3(grid), dim3(WAVES * 64), lds, st, p);
-  else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS>), dim3(grid), dim3(WAVES * 64), lds, st, p);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
 
 template <typename T, int STRIDE>
 int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* out, int B, int Hi, int Wi,
-                   bool relu, hipStream_t st, int Ho, int Wo) {
+                   bool relu, hipStream_t st, int Ho, int Wo, const ConvLayer* ds = nullptr, void* ds_out = nullptr) {
   Conv3Params p;
+  p.ds_w = ds ? ds->w_dev : nullptr; p.ds_scale = ds ? ds->scale_dev : nullptr;
+  p.ds_shift = ds ? ds->shift_dev : nullptr; p.ds_out = ds_out;
   p.in = in; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = out;
   p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = L.cin; p.Cout = L.cout; p.Ho = Ho; p.Wo = Wo;
   p.relu = relu ? 1 : 0;
@@ -777,7 +779,7 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     else { p.TH = 8; p.TW = 8; p.IMGS = 2; }
     p.HR = 2 * p.TH + 1; p.HC = 2 * p.TW + 1; p.HPH = p.TW + 1; p.HP = 2 * p.HPH;
     p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
-    rc = launch_conv3x3_cfg<T, 2, 1, 4>(p, L, st);
+    rc = ds ? launch_conv3x3_cfg<T, 2, 1, 4, true>(p, L, st) : launch_conv3x3_cfg<T, 2, 1, 4>(p, L, st);
   }
   if (rc) return rc;
   if (sample) {
@@ -902,13 +904,17 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
       const ConvLayer& c1 = net->convs[ci];
       const ConvLayer& c2 = net->convs[ci + 1];
       int Ho, Wo, h2, w2;
-      int rc = run_conv<T>(c1, bufA, nullptr, bufB, B, H, W, true, st, &Ho, &Wo);
-      if (rc) return rc;
+      int rc;
       const void* resid = bufA;
       if (has_ds) {
-        rc = run_conv<T>(net->convs[ci + 2], bufA, nullptr, bufC, B, H, W, false, st, &h2, &w2);
+        // conv1 (3x3/2 + BN + ReLU) and the 1x1/2 downsample (+ BN) of the block in ONE launch
+        Ho = (H + 2 - 3) / 2 + 1; Wo = (W + 2 - 3) / 2 + 1;
+        rc = launch_conv3x3<T, 2>(c1, bufA, nullptr, bufB, B, H, W, true, st, Ho, Wo, &net->convs[ci + 2], bufC);
         if (rc) return rc;
         resid = bufC;
+      } else {
+        rc = run_conv<T>(c1, bufA, nullptr, bufB, B, H, W, true, st, &Ho, &Wo);
+        if (rc) return rc;
       }
       rc = run_conv<T>(c2, bufB, resid, bufA, B, Ho, Wo, true, st, &h2, &w2);
       if (rc) return rc;
