@@ -6,6 +6,7 @@
 // All of these are HBM-bound byte/integer work: no LDS, no MFMA; the design
 // rules are full-width coalesced rows (one wave = one tile row) and 16-byte stores.
 #include <stdarg.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -425,52 +426,66 @@ extern "C" int dh_accumulate_logits(const float* logits, const int32_t* yx_host,
   if (dh_ == 0 || dw_ == 0) return DH_OK;
   DH_REQUIRE(dh_ * dw_ <= (int64_t)INT32_MAX, "accumulate: canvas too large");
   if (n > 0) {
-    const int G = std::max(1, std::min(P / d, 64));
-    const int64_t bins_y = (dh_ + G - 1) / G, bins_x = (dw_ + G - 1) / G;
-    const int64_t nbins = bins_y * bins_x;
-    DH_REQUIRE(nbins < INT32_MAX, "accumulate: too many bins");
-    std::vector<int32_t> start(nbins + 1, 0);
-    auto span = [&](int64_t i, int64_t& cy0, int64_t& cy1, int64_t& cx0, int64_t& cx1) {
-      const int64_t y = yx_host[2 * i], x = yx_host[2 * i + 1];
-      cy0 = std::max<int64_t>(y / d, 0); cy1 = std::min<int64_t>((y + P) / d, dh_);
-      cx0 = std::max<int64_t>(x / d, 0); cx1 = std::min<int64_t>((x + P) / d, dw_);
-      return y >= 0 && x >= 0 && cy1 > cy0 && cx1 > cx0;
+    // The bin lists depend only on (origins, P, d, h, w): whole-slide prediction repeats the same
+    // grid slide after slide, so the last plan (host CSR + its device copies) is kept and reused
+    // when the origins compare equal -- no rebuild, no upload, no stream synchronisation.
+    struct Plan {
+      std::vector<int32_t> yx; int32_t P = 0, d = 0; int64_t h = 0, w = 0, nbins = 0, total = 0; int G = 0, bins_x = 0;
+      int32_t *d_start = nullptr, *d_tiles = nullptr, *d_yx = nullptr; int device = -1;
     };
-    int64_t total = 0;
-    for (int64_t i = 0; i < n; ++i) {
-      int64_t a, b, c, e;
-      DH_REQUIRE(yx_host[2 * i] >= 0 && yx_host[2 * i + 1] >= 0, "accumulate: negative origin");
-      if (!span(i, a, b, c, e)) continue;
-      for (int64_t by = a / G; by <= (b - 1) / G; ++by)
-        for (int64_t bx = c / G; bx <= (e - 1) / G; ++bx) { ++start[by * bins_x + bx + 1]; ++total; }
+    static thread_local Plan plan;
+    int dev_id = 0;
+    DH_HIP(hipGetDevice(&dev_id));
+    const bool hit = plan.device == dev_id && plan.P == P && plan.d == d && plan.h == h && plan.w == w &&
+                     (int64_t)plan.yx.size() == 2 * n && memcmp(plan.yx.data(), yx_host, (size_t)n * 8) == 0;
+    if (!hit) {
+      const int G = std::max(1, std::min(P / d, 64));
+      const int64_t bins_y = (dh_ + G - 1) / G, bins_x = (dw_ + G - 1) / G;
+      const int64_t nbins = bins_y * bins_x;
+      DH_REQUIRE(nbins < INT32_MAX, "accumulate: too many bins");
+      std::vector<int32_t> start(nbins + 1, 0);
+      auto span = [&](int64_t i, int64_t& cy0, int64_t& cy1, int64_t& cx0, int64_t& cx1) {
+        const int64_t y = yx_host[2 * i], x = yx_host[2 * i + 1];
+        cy0 = std::max<int64_t>(y / d, 0); cy1 = std::min<int64_t>((y + P) / d, dh_);
+        cx0 = std::max<int64_t>(x / d, 0); cx1 = std::min<int64_t>((x + P) / d, dw_);
+        return y >= 0 && x >= 0 && cy1 > cy0 && cx1 > cx0;
+      };
+      int64_t total = 0;
+      for (int64_t i = 0; i < n; ++i) {
+        int64_t a, b, c, e;
+        DH_REQUIRE(yx_host[2 * i] >= 0 && yx_host[2 * i + 1] >= 0, "accumulate: negative origin");
+        if (!span(i, a, b, c, e)) continue;
+        for (int64_t by = a / G; by <= (b - 1) / G; ++by)
+          for (int64_t bx = c / G; bx <= (e - 1) / G; ++bx) { ++start[by * bins_x + bx + 1]; ++total; }
+      }
+      DH_REQUIRE(total < INT32_MAX, "accumulate: incidence list too long");
+      for (int64_t b = 0; b < nbins; ++b) start[b + 1] += start[b];
+      std::vector<int32_t> fill(start.begin(), start.end() - 1), tiles((size_t)std::max<int64_t>(total, 1));
+      for (int64_t i = 0; i < n; ++i) {
+        int64_t a, b, c, e;
+        if (!span(i, a, b, c, e)) continue;
+        for (int64_t by = a / G; by <= (b - 1) / G; ++by)
+          for (int64_t bx = c / G; bx <= (e - 1) / G; ++bx) tiles[fill[by * bins_x + bx]++] = (int32_t)i;
+      }
+      DH_HIP(hipStreamSynchronize(st));  // the previous plan's buffers may still be in use on this stream
+      if (plan.d_start) { (void)hipFree(plan.d_start); (void)hipFree(plan.d_tiles); (void)hipFree(plan.d_yx); }
+      plan = Plan();
+      const size_t sb = (size_t)(nbins + 1) * 4, tb = (size_t)std::max<int64_t>(total, 1) * 4, yb = (size_t)n * 8;
+      DH_HIP(hipMalloc((void**)&plan.d_start, sb));
+      DH_HIP(hipMalloc((void**)&plan.d_tiles, tb));
+      DH_HIP(hipMalloc((void**)&plan.d_yx, yb));
+      DH_HIP(hipMemcpy(plan.d_start, start.data(), sb, hipMemcpyHostToDevice));
+      DH_HIP(hipMemcpy(plan.d_tiles, tiles.data(), tb, hipMemcpyHostToDevice));
+      DH_HIP(hipMemcpy(plan.d_yx, yx_host, yb, hipMemcpyHostToDevice));
+      plan.yx.assign(yx_host, yx_host + 2 * n);
+      plan.P = P; plan.d = d; plan.h = h; plan.w = w; plan.nbins = nbins; plan.total = total; plan.G = G;
+      plan.bins_x = (int)bins_x; plan.device = dev_id;
     }
-    DH_REQUIRE(total < INT32_MAX, "accumulate: incidence list too long");
-    for (int64_t b = 0; b < nbins; ++b) start[b + 1] += start[b];
-    std::vector<int32_t> fill(start.begin(), start.end() - 1), tiles((size_t)std::max<int64_t>(total, 1));
-    for (int64_t i = 0; i < n; ++i) {
-      int64_t a, b, c, e;
-      if (!span(i, a, b, c, e)) continue;
-      for (int64_t by = a / G; by <= (b - 1) / G; ++by)
-        for (int64_t bx = c / G; bx <= (e - 1) / G; ++bx) tiles[fill[by * bins_x + bx]++] = (int32_t)i;
-    }
-    if (total > 0) {
-      int32_t *d_start = nullptr, *d_tiles = nullptr, *d_yx = nullptr;
-      const size_t sb = (size_t)(nbins + 1) * 4, tb = (size_t)total * 4, yb = (size_t)n * 8;
-      DH_HIP(hipMallocAsync((void**)&d_start, sb, st));
-      DH_HIP(hipMallocAsync((void**)&d_tiles, tb, st));
-      DH_HIP(hipMallocAsync((void**)&d_yx, yb, st));
-      DH_HIP(hipMemcpyAsync(d_start, start.data(), sb, hipMemcpyHostToDevice, st));
-      DH_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tb, hipMemcpyHostToDevice, st));
-      DH_HIP(hipMemcpyAsync(d_yx, yx_host, yb, hipMemcpyHostToDevice, st));
-      BinGeom g{G, (int32_t)bins_x, (int32_t)dh_, (int32_t)dw_, n_cls, P, d};
-      hipLaunchKernelGGL(accumulate_bins_kernel, dim3((unsigned)nbins), dim3(256), 0, st, logits, d_yx,
-                         d_start, d_tiles, g, canvas);
+    if (plan.total > 0) {
+      BinGeom g{plan.G, (int32_t)plan.bins_x, (int32_t)dh_, (int32_t)dw_, n_cls, P, d};
+      hipLaunchKernelGGL(accumulate_bins_kernel, dim3((unsigned)plan.nbins), dim3(256), 0, st, logits, plan.d_yx,
+                         plan.d_start, plan.d_tiles, g, canvas);
       DH_LAUNCH_CHECK();
-      DH_HIP(hipFreeAsync(d_start, st));
-      DH_HIP(hipFreeAsync(d_tiles, st));
-      DH_HIP(hipFreeAsync(d_yx, st));
-      // the host vectors above feed async copies: keep them alive until the stream drains
-      DH_HIP(hipStreamSynchronize(st));
     }
   }
   if (map) return dh_argmax_map(canvas, dh_ * dw_, n_cls, map, stream);

@@ -94,7 +94,10 @@ int dh_tile_coords_f32(const int32_t* yx_dev, int64_t n, float* out_dev, void* s
  * logits_dev: float32[n][n_cls]; canvas_dev: float32[dh][dw][n_cls] (accumulated
  * into -- zero it first for a fresh prediction), dh = h/d, dw = w/d (floor).
  * map_dev (optional, may be NULL): int64[dh][dw] = first index of the maximum
- * over classes of the updated canvas (NumPy argmax tie/NaN rule). */
+ * over classes of the updated canvas (NumPy argmax tie/NaN rule).
+ * The per-bin tile lists built from yx_host are cached per thread and reused while the same
+ * origins are passed again (whole-slide prediction repeats one grid): such calls are fully
+ * asynchronous; a call with new origins synchronises the stream once. */
 int dh_accumulate_logits(const float* logits_dev, const int32_t* yx_host, int64_t n,
                          int32_t patch, int32_t downscale, int32_t n_cls, int64_t h, int64_t w,
                          float* canvas_dev, int64_t* map_dev, void* stream);
