@@ -650,10 +650,10 @@ void* g_zero_page = nullptr;  // 1 KiB of zeros: DMA source of padding pixels
 struct Conv3Tables { int* lane = nullptr; int4* tile = nullptr; };
 std::map<std::vector<int>, Conv3Tables> g_conv3_tables;
 
-template <int STRIDE, int NT, int WAVES, int ESZ>
+template <int STRIDE, int NT, int WAVES, int ESZ, int MT>
 int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out) {
-  constexpr int MAXJ = (STRIDE == 2) ? 10 : (NT == 2 ? 6 : 4);
-  const std::vector<int> key = {STRIDE, NT, WAVES, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi, p.Cin,
+  constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
+  const std::vector<int> key = {STRIDE, NT, WAVES, MT, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi, p.Cin,
                                 p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr};
   auto it = g_conv3_tables.find(key);
   if (it != g_conv3_tables.end()) { *out = it->second; return DH_OK; }
@@ -663,7 +663,7 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
     const int l = tid & 63, wave = tid >> 6;
     int* row = &lane[(size_t)tid * stride];
     for (int nt = 0; nt < NT; ++nt) {
-      const int pidx = (wave * NT + nt) * 32 + (l & 31);
+      const int pidx = ((MT == 2 ? wave : wave >> 1) * NT + nt) * 32 + (l & 31);   // MT == 1: wave pairs share pixels
       const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
       const int ty = rem / p.TW, tx = rem % p.TW;
       row[2 * nt] = ty | (tx << 8) | (img << 16);
@@ -701,35 +701,35 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
   return DH_OK;
 }
 
-template <typename T, int STRIDE, int NT, int WAVES, bool DS = false>
+template <typename T, int STRIDE, int NT, int WAVES, bool DS = false, int MT = 2>
 int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   const int win_bytes = p.IMGS * p.HR * p.HP * CHUNK_BYTES;
   const size_t buf = (size_t)(9 + (DS ? 1 : 0)) * SLAB_TAP + ((win_bytes + 1023) & ~1023);
   const size_t lds = 2 * buf + (DS ? 2048 : 1024);  // 2-deep ring + [2][scale|shift(|ds scale|ds shift)]
-  constexpr int MAXJ = (STRIDE == 2) ? 10 : (NT == 2 ? 6 : 4);
+  constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
   p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
   DH_REQUIRE(p.n_win_instr <= MAXJ * WAVES, "conv3x3: staging window too large for the DMA plan");
   DH_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS budget exceeded (%zu B)", lds);
-  DH_REQUIRE(p.IMGS * p.TH * p.TW == WAVES * NT * 32, "conv3x3: tile/pixel mismatch");
+  DH_REQUIRE(p.IMGS * p.TH * p.TW == (WAVES * MT / 2) * NT * 32, "conv3x3: tile/pixel mismatch");
   DH_REQUIRE(L.cin * (int)sizeof(T) >= 2 * CHUNK_BYTES, "conv3x3: needs at least two channel chunks");
   const int groups = ((p.B + p.IMGS - 1) / p.IMGS) * p.tiles_y * p.tiles_x;
   p.ntiles = groups * (L.cout / 64);
   const int grid = std::min(256, p.ntiles);  // persistent: one workgroup per CU
   p.iters = (p.ntiles + grid - 1) / grid;
   Conv3Tables tb;
-  int rc = conv3_tables<STRIDE, NT, WAVES, (int)sizeof(T)>(p, L.cout / 64, groups, &tb);
+  int rc = conv3_tables<STRIDE, NT, WAVES, (int)sizeof(T), MT>(p, L.cout / 64, groups, &tb);
   if (rc) return rc;
   p.lane_tab = tb.lane; p.tile_tab = tb.tile;
   static bool attr_set = false;
   if (!attr_set) {
-    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS>),
+    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS>),
+    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS>), dim3(grid), dim3(WAVES * 64), lds, st, p);
-  else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT>), dim3(grid), dim3(WAVES * 64), lds, st, p);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
@@ -779,7 +779,8 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     else { p.TH = 8; p.TW = 8; p.IMGS = 2; }
     p.HR = 2 * p.TH + 1; p.HC = 2 * p.TW + 1; p.HPH = p.TW + 1; p.HP = 2 * p.HPH;
     p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
-    rc = ds ? launch_conv3x3_cfg<T, 2, 1, 4, true>(p, L, st) : launch_conv3x3_cfg<T, 2, 1, 4>(p, L, st);
+    // 128-pixel tiles, 8 waves: wave pairs share pixels and split the 64 couts (two waves per SIMD)
+    rc = ds ? launch_conv3x3_cfg<T, 2, 1, 8, true, 1>(p, L, st) : launch_conv3x3_cfg<T, 2, 1, 8, false, 1>(p, L, st);
   }
   if (rc) return rc;
   if (sample) {
