@@ -844,7 +844,7 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
     sp.B = B; sp.P = P; sp.Hc = H1; sp.Wc = H1; sp.Hp = H2; sp.Wp = H2;
     sp.tiles_y = (H2 + SP_PR - 1) / SP_PR; sp.tiles_x = (H2 + SP_PC - 1) / SP_PC;
     sp.ntiles = B * sp.tiles_y * sp.tiles_x;
-    const int grid = std::min(256, sp.ntiles);
+    const int grid = std::min(512, sp.ntiles);   // persistent: two 4-wave workgroups per CU
     sp.iters = (sp.ntiles + grid - 1) / grid;
     static bool a = false;
     if (!a) {
@@ -861,9 +861,9 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
       }
       sp.stamps = g_stamps_dev + 8 * 7;
     }
-    if (slide && sp.stamps) hipLaunchKernelGGL((stem_pool_kernel<true, true>), dim3(grid), dim3(512), SP_LDS, st, sp);
-    else if (slide) hipLaunchKernelGGL((stem_pool_kernel<true, false>), dim3(grid), dim3(512), SP_LDS, st, sp);
-    else hipLaunchKernelGGL((stem_pool_kernel<false, false>), dim3(grid), dim3(512), SP_LDS, st, sp);
+    if (slide && sp.stamps) hipLaunchKernelGGL((stem_pool_kernel<true, true>), dim3(grid), dim3(SP_T), SP_LDS, st, sp);
+    else if (slide) hipLaunchKernelGGL((stem_pool_kernel<true, false>), dim3(grid), dim3(SP_T), SP_LDS, st, sp);
+    else hipLaunchKernelGGL((stem_pool_kernel<false, false>), dim3(grid), dim3(SP_T), SP_LDS, st, sp);
     DH_LAUNCH_CHECK();
   } else {
   // stem

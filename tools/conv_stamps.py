@@ -23,7 +23,7 @@ for _ in range(3):
 out = np.zeros(64, np.uint64)
 check(lib().dh_debug_stamps(0, out.ctypes.data), "stamps read")
 names = ["s1 cin64", "s1 cin128", "s1 cin256", "s1 cin512", "s2 cin64", "s2 cin128", "s2 cin256",
-         "stem+pool (slots: prefetch, mfma, epilogue, barrier, pool, stage+barrier)"]
+         "stem+pool (slots: prefetch, mfma, bn+pool, stores, stage, barrier)"]
 print("row           wgs   cyc/wg  cursor%  epil%  mfma%  barr%  prolog% tail%")
 for r, n in enumerate(names):
     v = out[8 * r:8 * r + 8].astype(np.float64)
