@@ -32,6 +32,7 @@ SIGNATURES = {
     "dh_synth_slide": (C.c_int, [_p, _i64, _i64, _u32, _p]),
     "dh_tile_gather": (C.c_int, [_p, _i64, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
     "dh_tile_gather_aug": (C.c_int, [_p, _i64, _i64, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "dh_tile_gather_raw": (C.c_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _p]),
     "dh_tile_coords_f32": (C.c_int, [_p, _i64, _p, _p]),
     "dh_accumulate_logits": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i64, _i64, _p, _p, _p]),
     "dh_argmax_map": (C.c_int, [_p, _i64, _i32, _p, _p]),

@@ -327,6 +327,31 @@ extern "C" int dh_tile_gather_aug(const uint8_t* slide, int64_t h, int64_t w, co
   return DH_OK;
 }
 
+// NHWC float32 WITHOUT the /255 (FullImageRndSampler.generator_torch, full_samplers.py:286, yields the
+// raw 0..255 values as floats -- unlike the dense sampler).
+__global__ __launch_bounds__(256) void gather_raw_nhwc_kernel(const uint8_t* __restrict__ slide, int64_t row_bytes,
+                                                              const int32_t* __restrict__ yx, int P, float* __restrict__ out) {
+  const int t = blockIdx.y;
+  const int y0 = yx[2 * t], x0 = yx[2 * t + 1];
+  const int64_t per_tile = (int64_t)P * P * 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_tile; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (3 * P)), rem = (int)(i - (int64_t)r * 3 * P);
+    out[(int64_t)t * per_tile + i] = (float)slide[(int64_t)(y0 + r) * row_bytes + (int64_t)x0 * 3 + rem];
+  }
+}
+
+extern "C" int dh_tile_gather_raw(const uint8_t* slide, int64_t h, int64_t w, const int32_t* yx_dev, int64_t n, int32_t P,
+                                  float* out, void* stream) {
+  DH_REQUIRE(n >= 0 && n <= 65535, "tile gather raw: n=%lld out of range", (long long)n);
+  if (n == 0) return DH_OK;
+  DH_REQUIRE(slide && yx_dev && out && P > 0 && h >= P && w >= P, "tile gather raw: bad arguments");
+  const int64_t per_tile = (int64_t)P * P * 3;
+  dim3 grid((unsigned)std::min<int64_t>((per_tile + 255) / 256, 1024), (unsigned)n), block(256);
+  hipLaunchKernelGGL(gather_raw_nhwc_kernel, grid, block, 0, dh::as_stream(stream), slide, w * 3, yx_dev, P, out);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
 __global__ void coords_kernel(const int32_t* __restrict__ yx, int64_t n2, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n2) out[i] = (float)yx[i];

@@ -57,17 +57,10 @@ class DevicePatch(Patch):
         return f"DevicePatch(layer={self.layer}, pos_x={self.pos_x}, pos_y={self.pos_y}, patch_size={self.patch_size})"
 
 
-class FullImageDenseSampler:
-    def __init__(
-        self,
-        psimage_path,
-        layer: int,
-        patch_size: int,
-        batch_size: int,
-        mode: SamplerExecutionMode = SamplerExecutionMode.INMEMORY_SINGLEPROC,
-        stride: int = None,
-        device="cuda",
-    ):
+class _SlideHolder:
+    """Shared slide residency (host array / HBM tensor) of the full-slide samplers."""
+
+    def _open(self, psimage_path, layer, mode, device):
         self._psim_path = psimage_path
         self.mode = mode
         self.layer = layer
@@ -94,16 +87,7 @@ class FullImageDenseSampler:
             raise NotImplementedError(
                 "ONDISK_MULTIPROC streaming from .psi files is not built yet (SURVEY section 8f row 3); "
                 "use INMEMORY_SINGLEPROC")
-        self.patch_size = int(patch_size)
-        self.batch_size = int(batch_size)
-        self.stride = int(stride) if stride is not None else int(patch_size)
-        if self.h < self.patch_size or self.w < self.patch_size:
-            raise ValueError(f"slide {self.h}x{self.w} is smaller than the patch {self.patch_size}")
-        self._origins, self.n_tiles = tiles.tile_grid(self.h, self.w, self.patch_size, self.stride,
-                                                      self.batch_size)
-        print(f"Image {self.h} x {self.w}")
 
-    # ---- slide residency ------------------------------------------------------------
     @property
     def data(self) -> np.ndarray:
         """uint8[h, w, 3] host array of the layer (reference attribute, :319-320)."""
@@ -117,6 +101,100 @@ class FullImageDenseSampler:
         if self._dev is None:
             self._dev = torch.from_numpy(self._host).to(self.device)
         return self._dev
+
+
+class FullImageRndSampler(_SlideHolder):
+    """Coverage-driven random tile sampler -- drop-in for full_samplers.py:21-299.
+
+    Keeps a `dh x dw` hit-count map at `speedup`x downscale and draws `batch_size` tile origins
+    per batch from the cells hit fewer than `dense_level` times, until every cell was hit.  The
+    index logic runs on the host and consumes the GLOBAL NumPy RNG with the reference's calls in
+    the reference's order (so `np.random.seed(s)` reproduces the reference's origins); pixels
+    stay in HBM (`DevicePatch`, `dh_tile_gather_raw`).  `generator_torch` yields the raw 0..255
+    floats like the reference (:286 has no /255)."""
+
+    def __init__(self, psimage_path, layer: int, patch_size: int, batch_size: int,
+                 mode: SamplerExecutionMode = SamplerExecutionMode.INMEMORY_SINGLEPROC,
+                 dense_level: int = 2, speedup: int = 16, device="cuda"):
+        self._open(psimage_path, layer, mode, device)
+        self.dh, self.dw = self.h // speedup, self.w // speedup
+        print(f"Image {self.h} x {self.w} at {speedup}x -> {self.dh} x {self.dw}")
+        self.patch_size = int(patch_size)
+        self.batch_size = int(batch_size)
+        self._downscale = int(speedup)
+        self.dense_level = dense_level
+        self._filled_ratio = []
+        self._accum = None
+        if self.h < self.patch_size or self.w < self.patch_size:
+            raise ValueError(f"slide {self.h}x{self.w} is smaller than the patch {self.patch_size}")
+
+    def _calc_probmap(self):
+        p = np.where(self._accum >= self.dense_level, 0, 1)
+        if np.count_nonzero(p) < self.batch_size:
+            while np.count_nonzero(p) < self.batch_size:
+                p[np.random.randint(0, p.shape[0], size=1), np.random.randint(0, p.shape[1], size=1)] = 1
+        return p / np.sum(p)
+
+    def _prepare_indices(self, probmap):
+        d, P = self._downscale, self.patch_size
+        idx = list(np.random.choice(self.dh * self.dw, size=self.batch_size, replace=False, p=probmap.flatten()))
+        pd2 = P // d // 2
+        out = []
+        for ind in idx:  # y jitter first, then x, one randint each (reference order)
+            y = (ind // self.dw - pd2) * d + np.random.randint(d)
+            x = (ind % self.dw - pd2) * d + np.random.randint(d)
+            out.append((max(min(y, self.h - P), 0), max(min(x, self.w - P), 0)))
+        return out
+
+    def _update_accum(self, origins):
+        d, s = self._downscale, self.patch_size
+        for y, x in origins:
+            self._accum[y // d:(y + s) // d, x // d:(x + s) // d] += 1
+        return np.count_nonzero(self._accum) / self._accum.size
+
+    def _origin_batches(self):
+        self._accum = np.zeros([self.dh, self.dw], dtype=np.float32)
+        filled = 0
+        while filled < 1:
+            origins = self._prepare_indices(self._calc_probmap())
+            filled = self._update_accum(origins)
+            self._filled_ratio.append(filled)
+            yield origins, filled
+
+    def __iter__(self) -> Iterator[tuple[list[Patch], float]]:
+        return self.generator()
+
+    def generator(self) -> Iterator[tuple[list[Patch], float]]:
+        for origins, filled in self._origin_batches():
+            yield [DevicePatch(self.layer, int(x), int(y), self.patch_size, self) for y, x in origins], filled
+
+    def generator_torch(self) -> Iterator[tuple[torch.Tensor, torch.Tensor, float]]:
+        slide = self.data_device
+        for origins, filled in self._origin_batches():
+            o_dev = torch.tensor(origins, dtype=torch.int32, device=slide.device)
+            yield tiles.gather_tiles_raw(slide, o_dev, self.patch_size), tiles.tile_coords(o_dev), filled
+
+
+class FullImageDenseSampler(_SlideHolder):
+    def __init__(
+        self,
+        psimage_path,
+        layer: int,
+        patch_size: int,
+        batch_size: int,
+        mode: SamplerExecutionMode = SamplerExecutionMode.INMEMORY_SINGLEPROC,
+        stride: int = None,
+        device="cuda",
+    ):
+        self._open(psimage_path, layer, mode, device)
+        self.patch_size = int(patch_size)
+        self.batch_size = int(batch_size)
+        self.stride = int(stride) if stride is not None else int(patch_size)
+        if self.h < self.patch_size or self.w < self.patch_size:
+            raise ValueError(f"slide {self.h}x{self.w} is smaller than the patch {self.patch_size}")
+        self._origins, self.n_tiles = tiles.tile_grid(self.h, self.w, self.patch_size, self.stride,
+                                                      self.batch_size)
+        print(f"Image {self.h} x {self.w}")
 
     # ---- grid ------------------------------------------------------------------------
     @property

@@ -94,6 +94,17 @@ def gather_tiles_aug(slide: torch.Tensor, origins_dev: torch.Tensor, patch: int,
     return out
 
 
+def gather_tiles_raw(slide: torch.Tensor, origins_dev: torch.Tensor, patch: int) -> torch.Tensor:
+    """float32[n, P, P, 3] of the raw 0..255 pixel values (FullImageRndSampler.generator_torch)."""
+    _require_cuda(slide, "slide")
+    _require_cuda(origins_dev, "origins")
+    n = int(origins_dev.shape[0])
+    out = torch.empty((n, patch, patch, 3), dtype=torch.float32, device=slide.device)
+    check(lib().dh_tile_gather_raw(slide.data_ptr(), int(slide.shape[0]), int(slide.shape[1]), origins_dev.data_ptr(), n,
+                                   patch, out.data_ptr(), _stream(slide.device)), "dh_tile_gather_raw")
+    return out
+
+
 def tile_coords(origins_dev: torch.Tensor) -> torch.Tensor:
     """float32[n, 2] (pos_y, pos_x) from int32 device origins (full_samplers.py:444-451)."""
     _require_cuda(origins_dev, "origins")

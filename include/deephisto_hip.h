@@ -82,6 +82,11 @@ int dh_tile_gather_aug(const uint8_t* slide_dev, int64_t h, int64_t w, const int
                        int64_t n, int32_t patch, int32_t layout, int32_t dtype, int32_t flip_h,
                        int32_t flip_v, void* out_dev, void* stream);
 
+/* FullImageRndSampler.generator_torch (full_samplers.py:277-290) stacks the uint8 patches into a
+ * float tensor WITHOUT dividing by 255: float32[n][P][P][3] with values 0..255. */
+int dh_tile_gather_raw(const uint8_t* slide_dev, int64_t h, int64_t w, const int32_t* yx_dev,
+                       int64_t n, int32_t patch, float* out_dev, void* stream);
+
 /* coords tensor of generator_torch (full_samplers.py:444-451): float32[n][2]. */
 int dh_tile_coords_f32(const int32_t* yx_dev, int64_t n, float* out_dev, void* stream);
 

@@ -135,7 +135,7 @@ def main():
 
     _install_standins()
     sys.path.insert(0, args.reference)
-    from patch_samplers.full_samplers import FullImageDenseSampler, SamplerExecutionMode
+    from patch_samplers.full_samplers import FullImageDenseSampler, FullImageRndSampler, SamplerExecutionMode
     from examples.predict_full_patched import ImagePredictorPatched, batch_predictor
 
     meta: dict = {"generator": "oracle/make_golden.py", "reference": "xubiker/deephisto@2025-02-22"}
@@ -244,6 +244,34 @@ def main():
         preds[name] = {"h": h, "w": w, "patch": p, "stride": s, "batch": b, "downscale": d,
                        "seed": seed, "map_shape": list(cmap.shape), "toy_model_seed": 7}
     meta["predict"] = preds
+
+    # ---- (4) next row f1: FullImageRndSampler under a fixed NumPy seed (full_samplers.py:21-299)
+    rnd = {}
+    for name, (h, w, p, b, dl, sp, seed, npseed) in {
+        "r700x900_128_8": (700, 900, 128, 8, 2, 16, 5, 1234),
+        "r512x640_96_4_dl1": (512, 640, 96, 4, 1, 16, 6, 99),
+    }.items():
+        _SLIDES[name] = synth_slide(h, w, seed)
+        np.random.seed(npseed)
+        smp = FullImageRndSampler(name, layer=1, patch_size=p, batch_size=b,
+                                  mode=SamplerExecutionMode.INMEMORY_SINGLEPROC, dense_level=dl, speedup=sp)
+        origins, ratios, u8 = [], [], []
+        for patches, ratio in smp.generator():
+            origins.append([(q.pos_y, q.pos_x) for q in patches])
+            ratios.append(ratio)
+            u8.append(sha(np.stack([q.data for q in patches])))
+        farr[name + "_origins"] = np.array(origins, dtype=np.int32)
+        farr[name + "_ratios"] = np.array(ratios, dtype=np.float64)
+        np.random.seed(npseed)
+        smp2 = FullImageRndSampler(name, layer=1, patch_size=p, batch_size=b,
+                                   mode=SamplerExecutionMode.INMEMORY_SINGLEPROC, dense_level=dl, speedup=sp)
+        f0, c0, _ = next(smp2.generator_torch())
+        farr[name + "_torch_first_crop"] = f0.numpy()[:, :4, :4, :].copy()   # NOT divided by 255 (full_samplers.py:286)
+        farr[name + "_torch_first_coords"] = c0.numpy()
+        rnd[name] = {"h": h, "w": w, "patch": p, "batch": b, "dense_level": dl, "speedup": sp, "seed": seed,
+                     "np_seed": npseed, "n_batches": len(ratios), "u8_sha256": u8,
+                     "coords_dtype": str(c0.dtype), "features_dtype": str(f0.dtype)}
+    meta["random_sampler"] = rnd
 
     np.savez_compressed(out / "vectors.npz", **farr)
     (out / "golden.json").write_text(json.dumps(meta, indent=1, sort_keys=True))

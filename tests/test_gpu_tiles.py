@@ -97,6 +97,43 @@ def test_sampler_generator_torch_matches_reference_fixture(dev, golden_meta, gol
             assert patches[0].data.base is not None
 
 
+def test_random_sampler_matches_reference_fixture(dev, golden_meta, golden_vectors):
+    """FullImageRndSampler under the recorded NumPy seed against what the REFERENCE's sampler drew
+    (origins, filled ratios, uint8 pixels; first generator_torch batch: raw 0..255 floats + coords)."""
+    from deephisto_amd.patch_samplers.full_samplers import FullImageRndSampler, SamplerExecutionMode
+    for name, r in golden_meta["random_sampler"].items():
+        host = synth.synth_slide(r["h"], r["w"], r["seed"])
+        mk = lambda: FullImageRndSampler(host, layer=1, patch_size=r["patch"], batch_size=r["batch"],
+                                         mode=SamplerExecutionMode.INMEMORY_SINGLEPROC, dense_level=r["dense_level"],
+                                         speedup=r["speedup"], device=dev)
+        np.random.seed(r["np_seed"])
+        smp = mk()
+        assert (smp.dh, smp.dw) == (r["h"] // r["speedup"], r["w"] // r["speedup"])
+        n = 0
+        for i, (patches, filled) in enumerate(smp):
+            got = np.array([(p.pos_y, p.pos_x) for p in patches], np.int32)
+            np.testing.assert_array_equal(got, golden_vectors[name + "_origins"][i])
+            assert filled == golden_vectors[name + "_ratios"][i]
+            assert sha(np.stack([p.data for p in patches])) == r["u8_sha256"][i]
+            n += 1
+        assert n == r["n_batches"] and smp._filled_ratio[-1] >= 1.0
+        # device iterator: same RNG stream -> same origins; features are the raw bytes as f32
+        np.random.seed(r["np_seed"])
+        smp = mk()
+        for i, (f, c, filled) in enumerate(smp.generator_torch()):
+            assert f.dtype == torch.float32 and tuple(f.shape) == (r["batch"], r["patch"], r["patch"], 3)
+            assert c.dtype == torch.float32
+            o = golden_vectors[name + "_origins"][i]
+            np.testing.assert_array_equal(c.cpu().numpy(), o.astype(np.float32))
+            want = tiling.gather_u8(host, o, r["patch"]).astype(np.float32)
+            np.testing.assert_array_equal(f.cpu().numpy(), want)
+            if i == 0:
+                np.testing.assert_array_equal(f[:, :4, :4, :].cpu().numpy(), golden_vectors[name + "_torch_first_crop"])
+                np.testing.assert_array_equal(c.cpu().numpy(), golden_vectors[name + "_torch_first_coords"])
+            assert filled == golden_vectors[name + "_ratios"][i]
+        assert i + 1 == r["n_batches"]
+
+
 @pytest.mark.parametrize("case", ["p1000x1300_256_256_16_d16", "p600x900_224_112_16_d16", "p700x500_100_60_8_d7"])
 def test_accumulate_and_argmax_bit_exact(dev, golden_meta, golden_vectors, case):
     from deephisto_amd import tiles

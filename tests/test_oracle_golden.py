@@ -101,3 +101,18 @@ def test_synth_formula_frozen():
          ^ ((2 * 2654435761) & 0xFFFFFFFF))
     assert big[1, 3, 2] == (v >> 7) & 0xFF
     assert sha(synth.synth_slide(64, 48, 1)) == sha(synth.synth_region(0, 0, 64, 48, 1))
+
+
+def test_random_sampler_oracle_matches_reference(golden_meta, golden_vectors):
+    """FullImageRndSampler under a fixed NumPy seed: origins, filled ratios, pixels."""
+    from oracle import random_sampler
+    for name, r in golden_meta["random_sampler"].items():
+        slide = synth.synth_slide(r["h"], r["w"], r["seed"])
+        np.random.seed(r["np_seed"])
+        got = list(random_sampler.random_batches(r["h"], r["w"], r["patch"], r["batch"], r["dense_level"], r["speedup"]))
+        assert len(got) == r["n_batches"]
+        np.testing.assert_array_equal(np.stack([o for o, _ in got]), golden_vectors[name + "_origins"])
+        np.testing.assert_array_equal(np.array([f for _, f in got]), golden_vectors[name + "_ratios"])
+        for (o, _), want in zip(got, r["u8_sha256"]):
+            assert sha(tiling.gather_u8(slide, o, r["patch"])) == want
+        assert got[-1][1] >= 1.0 and all(f < 1.0 for _, f in got[:-1])
