@@ -73,13 +73,13 @@ def host_cores() -> int:
 
 def cpu_baseline(args, budget_s: float) -> dict:
     """The oracle (port of the reference's CPU path a1->a8) on a bounded sample: the first
-    tiles of a 4096x4096 closed-form slide, whole batches, until the budget is spent."""
+    tiles of an 8192x8192 closed-form slide, whole batches, until the budget is spent."""
     from oracle import resnet18 as oracle_net
     from oracle import synth, tiling
 
     threads = host_cores()
     torch.set_num_threads(threads)
-    side = 4096
+    side = 8192
     host = synth.synth_slide(side, side, args.seed)
     net = oracle_net.seeded_model(0, 5).eval()
     batches = tiling.batched_origins(side, side, args.patch, args.stride, args.batch)
