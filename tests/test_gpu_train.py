@@ -2,8 +2,10 @@
 torch-CPU oracle (oracle/resnet18.py, "parity unpinned" against torchvision).
 
 Tolerances (float32 compute, stated per SURVEY section 8d): logits <= 1e-4 abs; loss <= 1e-4
-after step 1 and <= 1e-3 after 3 steps; gradients <= 2e-3 of the tensor's max |grad| (wgrad
-sums over up to 10^5 pixels in a different order, with float atomics)."""
+after step 1 and <= 1e-3 after 3 steps; gradients: relative L2 error <= 2e-2 per tensor against a
+float64 run of the oracle (see the comment in test_forward_backward_matches_oracle)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -32,7 +34,7 @@ def _rel(a, b):
     return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
 
 
-@pytest.mark.parametrize("B,P", [(8, 64), (4, 128)])
+@pytest.mark.parametrize("B,P", [(8, 64), (4, 128), (3, 224)])
 def test_forward_backward_matches_oracle(dev, B, P):
     ref, m = _pair(dev, 11)
     g = torch.Generator().manual_seed(B * P)
@@ -53,21 +55,22 @@ def test_forward_backward_matches_oracle(dev, B, P):
             assert _rel(sd[k].cpu(), sr[k]) <= 1e-5, k
         if "tracked" in k:
             assert int(sd[k]) == int(sr[k]) == 1
-    # gradients, from the head down (localises a failing kernel)
-    ref_g = {k: p.grad for k, p in ref.named_parameters()}
+    # Gradients against a float64 run of the oracle.  A ReLU whose pre-activation is within float32 rounding of
+    # zero (|pre| ~ 1e-6; about one element per 10^5-element tensor) may switch differently in two float32
+    # implementations, and with a handful of images one switched element moves a max-norm by percents -- the
+    # float32 CPU oracle itself shows 1e-2 max-norm differences from float64 on these inputs (tools/grad_check.py).
+    # A switch high in the network then perturbs every gradient below it (relative L2 of a few 1e-3).  The per-tensor
+    # relative L2 error is robust to that and still exposes any real kernel error (O(0.1-1)).
+    ref64 = copy.deepcopy(ref).double()
+    ref64.zero_grad()
+    F.cross_entropy(ref64(x.double()), y).backward()
+    g64 = {k: p.grad for k, p in ref64.named_parameters()}
     worst = {}
     for k, p in m.named_parameters():
         assert p.grad is not None, k
-        worst[k] = _rel(p.grad.cpu(), ref_g[k])
-    order = ["fc.bias", "fc.weight", "layer4.1.bn2.bias", "layer4.1.bn2.weight", "layer4.1.conv2.weight",
-             "layer4.1.bn1.weight", "layer4.1.conv1.weight", "layer4.0.conv2.weight", "layer4.0.downsample.0.weight",
-             "layer4.0.conv1.weight", "layer3.1.conv2.weight", "layer2.0.conv1.weight", "layer1.0.conv1.weight",
-             "bn1.weight", "conv1.weight"]
-    for k in order:
-        assert worst[k] <= 2e-3, f"{k}: relative grad error {worst[k]:.3e}"
-    bad = {k: v for k, v in worst.items() if v > 2e-3}
+        worst[k] = float((p.grad.cpu().double() - g64[k]).norm()) / (float(g64[k].norm()) + 1e-300)
+    bad = {k: v for k, v in worst.items() if v > 2e-2}
     assert not bad, bad
-
 
 def test_three_adam_steps_torch_optimizer(dev):
     """The reference's loop shape: criterion + loss.backward() + torch.optim.Adam.step()."""
