@@ -207,7 +207,7 @@ class ResNet18HIP(nn.Module):
         if dirty:
             check(lib().dh_resnet18_train_repack(self._handle, stream), "dh_resnet18_train_repack")
 
-    def _native_forward_train(self, x):
+    def _native_forward_train(self, x, pull_stats=True):
         n, p = int(x.shape[0]), int(x.shape[2])
         st = self._stream(x.device)
         if self._handle is None or getattr(self, "_train_shape", None) is None:
@@ -220,12 +220,24 @@ class ResNet18HIP(nn.Module):
         self._push_changed_parameters(st)
         out = torch.empty((n, self.n_classes), dtype=torch.float32, device=x.device)
         check(lib().dh_resnet18_forward_train(h, x.data_ptr(), n, p, out.data_ptr(), st), "dh_resnet18_forward_train")
-        for name, buf in self.named_buffers():  # running statistics back into the module
-            if name.endswith("num_batches_tracked"):
-                buf += 1
-            else:
-                check(lib().dh_resnet18_train_tensor(h, name.encode(), 2, buf.data_ptr(), buf.numel(), 0, st), f"pull {name}")
+        self._stats_pending = getattr(self, "_stats_pending", 0) + 1
+        if pull_stats:
+            self._pull_running_stats()
         return out
+
+    def _pull_running_stats(self):
+        """Library running statistics -> module buffers (+ the batch counters owed since the last pull)."""
+        owed = getattr(self, "_stats_pending", 0)
+        if not owed or self._handle is None:
+            return
+        with torch.no_grad():
+            for name, buf in self.named_buffers():
+                if name.endswith("num_batches_tracked"):
+                    buf += owed
+                else:
+                    check(lib().dh_resnet18_train_tensor(self._handle, name.encode(), 2, buf.data_ptr(), buf.numel(), 0,
+                                                         self._stream(buf.device)), f"pull {name}")
+        self._stats_pending = 0
 
     def _native_backward(self, dlogits):
         h, st = self._handle, self._stream(dlogits.device)
@@ -254,7 +266,7 @@ class ResNet18HIP(nn.Module):
             raise RuntimeError("train_step needs .train() mode")
         x = x.detach().to(torch.float32).contiguous()
         labels = labels.to(device=x.device, dtype=torch.int64).contiguous()
-        logits = self._native_forward_train(x)
+        logits = self._native_forward_train(x, pull_stats=False)   # 40 small copies per step otherwise; pulled lazily
         st = self._stream(x.device)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         dl = torch.empty_like(logits)
@@ -270,7 +282,8 @@ class ResNet18HIP(nn.Module):
         return loss, logits
 
     def pull_parameters(self):
-        """Library masters -> nn.Parameters (after fused train_step calls)."""
+        """Library masters and running statistics -> nn.Parameters / buffers (after fused train_step calls)."""
+        self._pull_running_stats()
         if getattr(self, "_native_ahead", False):
             with torch.no_grad():
                 for name, prm in self.named_parameters():

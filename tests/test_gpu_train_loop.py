@@ -94,5 +94,6 @@ def test_train_mirror_runs_and_learns(dev, tmp_path):
     x = torch.rand(2, 3, 64, 64)
     with torch.no_grad():
         want = ref.eval()(x)
+    model.load_state_dict(ck)          # the checkpoint is the BEST epoch, the returned model the last one
     got = model.eval()(x.to(dev)).cpu()
     assert float((got - want).abs().max()) <= 2e-4
