@@ -761,19 +761,36 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
   }
   bool sample = false;
   // sampled: the dominant variant only (stride 1, 512-pixel tiles: layers 1-3)
-  if (STRIDE == 1 && Wo > 8 && g_prof.on && g_prof.used + 2 <= g_prof.ev.size() && (g_prof.counter++ % g_prof.every) == 0) {
-    sample = true;
-    DH_HIP(hipEventRecord(g_prof.ev[g_prof.used], st));
-  }
+  auto maybe_sample = [&](bool dominant) -> int {
+    if (dominant && g_prof.on && g_prof.used + 2 <= g_prof.ev.size() && (g_prof.counter++ % g_prof.every) == 0) {
+      sample = true;
+      DH_HIP(hipEventRecord(g_prof.ev[g_prof.used], st));
+    }
+    return DH_OK;
+  };
   int rc;
   if (STRIDE == 1) {
     p.HPH = 0;
-    if (Wo > 16) { p.TH = 16; p.TW = 32; p.IMGS = 1; p.HP = 34; }
-    else if (Wo > 8) { p.TH = 16; p.TW = 16; p.IMGS = 2; p.HP = 18; }
-    else { p.TH = 8; p.TW = 8; p.IMGS = 4; p.HP = 10; }
+    // 512-pixel tiles (NT = 2) when that still gives every CU a tile; small batches of small maps (training at
+    // batch 64: 14x14 and 7x7) drop to 256- and 128-pixel tiles instead of leaving half the chip idle
+    auto ntiles_of = [&](int th, int tw, int imgs) {
+      return ((B + imgs - 1) / imgs) * ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw) * (L.cout / 64);
+    };
+    int variant;  // 0: NT=2 MT=2 (512 px)   1: NT=1 MT=2 (256 px)   2: NT=1 MT=1 (128 px)
+    if (Wo > 16) { p.TH = 16; p.TW = 32; p.IMGS = 1; p.HP = 34; variant = 0; }
+    else if (Wo > 8) {
+      if (ntiles_of(16, 16, 2) >= 256) { p.TH = 16; p.TW = 16; p.IMGS = 2; p.HP = 18; variant = 0; }
+      else { p.TH = 16; p.TW = 16; p.IMGS = 1; p.HP = 18; variant = 1; }
+    } else {
+      if (ntiles_of(8, 8, 4) >= 256) { p.TH = 8; p.TW = 8; p.IMGS = 4; p.HP = 10; variant = 1; }
+      else { p.TH = 8; p.TW = 8; p.IMGS = 2; p.HP = 10; variant = 2; }
+    }
     p.HR = p.TH + 2; p.HC = p.TW + 2;
     p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
-    rc = (Wo > 8) ? launch_conv3x3_cfg<T, 1, 2, 8>(p, L, st) : launch_conv3x3_cfg<T, 1, 1, 8>(p, L, st);
+    if ((rc = maybe_sample(variant == 0))) return rc;
+    rc = variant == 0 ? launch_conv3x3_cfg<T, 1, 2, 8>(p, L, st)
+       : variant == 1 ? launch_conv3x3_cfg<T, 1, 1, 8>(p, L, st)
+                      : launch_conv3x3_cfg<T, 1, 1, 8, false, 1>(p, L, st);
   } else {
     if (Wo > 8) { p.TH = 8; p.TW = 16; p.IMGS = 1; }
     else { p.TH = 8; p.TW = 8; p.IMGS = 2; }
