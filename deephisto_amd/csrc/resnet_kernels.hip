@@ -662,8 +662,20 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
   for (int tid = 0; tid < threads; ++tid) {
     const int l = tid & 63, wave = tid >> 6;
     int* row = &lane[(size_t)tid * stride];
+    // Lane -> pixel of the n-tile.  A ds_read_b128 is served in two groups of 16 lanes per half-wave,
+    // A = {0-3, 12-15, 20-27} and B = {4-11, 16-19, 28-31}; the swizzled window image is conflict-free when the 16
+    // pixels of a group have 16 different (linear index mod 16).  Rows of 32 pixels satisfy that in lane order;
+    // 16- and 8-pixel rows do when group A takes rows {0} / {0, 2} and group B rows {1} / {1, 3} (row pitches are
+    // chosen so that those row pairs cover disjoint residues).
+    auto lane_pos = [&](int ll) {
+      if (p.TW >= 32) return ll;
+      const bool in_a = ll < 4 || (ll >= 12 && ll < 16) || (ll >= 20 && ll < 28);
+      const int rank = in_a ? (ll < 4 ? ll : ll < 16 ? ll - 8 : ll - 12) : (ll < 12 ? ll - 4 : ll < 20 ? ll - 8 : ll - 16);
+      if (p.TW == 16) return (in_a ? 0 : 16) + rank;
+      return (in_a ? 0 : 8) + (rank < 8 ? rank : rank + 8);   // TW == 8: A -> rows 0, 2; B -> rows 1, 3
+    };
     for (int nt = 0; nt < NT; ++nt) {
-      const int pidx = ((MT == 2 ? wave : wave >> 1) * NT + nt) * 32 + (l & 31);   // MT == 1: wave pairs share pixels
+      const int pidx = ((MT == 2 ? wave : wave >> 1) * NT + nt) * 32 + lane_pos(l & 31);   // MT == 1: wave pairs share pixels
       const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
       const int ty = rem / p.TW, tx = rem % p.TW;
       row[2 * nt] = ty | (tx << 8) | (img << 16);
@@ -777,13 +789,19 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
       return ((B + imgs - 1) / imgs) * ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw) * (L.cout / 64);
     };
     int variant;  // 0: NT=2 MT=2 (512 px)   1: NT=1 MT=2 (256 px)   2: NT=1 MT=1 (128 px)
-    if (Wo > 16) { p.TH = 16; p.TW = 32; p.IMGS = 1; p.HP = 34; variant = 0; }
+    if (Wo > 16) {
+      // 16x32 or 8x64 output pixels, whichever wastes fewer tile slots (56x56: 77 % vs 88 % useful)
+      const int slots_a = ((Ho + 15) / 16) * ((Wo + 31) / 32), slots_b = ((Ho + 7) / 8) * ((Wo + 63) / 64);
+      if (slots_b < slots_a) { p.TH = 8; p.TW = 64; p.IMGS = 1; p.HP = 66; }
+      else { p.TH = 16; p.TW = 32; p.IMGS = 1; p.HP = 34; }
+      variant = 0;
+    }
     else if (Wo > 8) {
       if (ntiles_of(16, 16, 2) >= 256) { p.TH = 16; p.TW = 16; p.IMGS = 2; p.HP = 18; variant = 0; }
       else { p.TH = 16; p.TW = 16; p.IMGS = 1; p.HP = 18; variant = 1; }
     } else {
-      if (ntiles_of(8, 8, 4) >= 256) { p.TH = 8; p.TW = 8; p.IMGS = 4; p.HP = 10; variant = 1; }
-      else { p.TH = 8; p.TW = 8; p.IMGS = 2; p.HP = 10; variant = 2; }
+      if (ntiles_of(8, 8, 4) >= 256) { p.TH = 8; p.TW = 8; p.IMGS = 4; p.HP = 12; variant = 1; }   // pitch 12: see lane_pos
+      else { p.TH = 8; p.TW = 8; p.IMGS = 2; p.HP = 12; variant = 2; }
     }
     p.HR = p.TH + 2; p.HC = p.TW + 2;
     p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
