@@ -879,7 +879,7 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
     sp.B = B; sp.P = P; sp.Hc = H1; sp.Wc = H1; sp.Hp = H2; sp.Wp = H2;
     sp.tiles_y = (H2 + SP_PR - 1) / SP_PR; sp.tiles_x = (H2 + SP_PC - 1) / SP_PC;
     sp.ntiles = B * sp.tiles_y * sp.tiles_x;
-    const int grid = std::min(512, sp.ntiles);   // persistent: two 4-wave workgroups per CU
+    const int grid = std::min(768, sp.ntiles);   // persistent: three 4-wave workgroups per CU
     sp.iters = (sp.ntiles + grid - 1) / grid;
     static bool a = false;
     if (!a) {
