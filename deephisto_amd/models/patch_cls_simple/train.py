@@ -12,10 +12,10 @@ What moved to the GPU: the step itself (forward, CrossEntropy, backward, Adam: H
 once per epoch instead of four host syncs per step, train.py:174-180).
 
 Not reproduced: the ImageFolder test loop and the JPEG plots (train.py:253-301; disk I/O and
-matplotlib, out of scope), and the polygon annotations (shapely): the data source is any
-object with `device_batches(batch_size, n_batches)` such as `RectRegionRndSampler`; when
-`cfg["dataset"]["folder"]` does not exist a closed-form synthetic slide with rectangular
-regions is used (BASELINE configs[1]).
+matplotlib, out of scope).  The data source is any object with `device_batches(batch_size,
+n_batches)`: `AnnoRegionRndSampler` over `cfg["dataset"]["folder"]` when that folder exists (as
+in the reference, train.py:93-103; `.psi` images need the third-party psimage package), else a
+closed-form synthetic slide with rectangular regions (`RectRegionRndSampler`, BASELINE configs[1]).
 """
 from __future__ import annotations
 
@@ -26,7 +26,7 @@ import torch
 
 from . import utils
 from .model import get_model
-from ...patch_samplers.region_samplers import RectRegionRndSampler, synthetic_regions
+from ...patch_samplers.region_samplers import AnnoRegionRndSampler, RectRegionRndSampler, synthetic_regions
 
 
 def _synthetic_sampler(cfg, device):
@@ -67,10 +67,14 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
 
     if sampler is None:
         folder = Path(cfg["dataset"]["folder"])
-        if folder.exists():
-            raise NotImplementedError("reading annotated .psi datasets needs psimage + polygon geometry "
-                                      "(SURVEY section 8f row 2); pass a sampler or use the synthetic source")
-        sampler = _synthetic_sampler(cfg, device)
+        if folder.exists():   # the reference's data source (train.py:93-103); .psi files need the psimage package
+            sampler = AnnoRegionRndSampler(utils.get_img_ano_paths(folder, sample="train"),
+                                           patch_size=cfg["dataset"]["patch_size"], layer=cfg["dataset"]["layer"],
+                                           patches_from_one_region=cfg["dataset"]["patches_from_one_region"],
+                                           one_image_for_batch=cfg["training"].get("one_image_for_batch", False),
+                                           device=device)
+        else:
+            sampler = _synthetic_sampler(cfg, device)
 
     bs = cfg["training"]["batch_size"]
     model = get_model(cfg["model"]["n_classes"], cfg.get("runtime", {}).get("compute_dtype", "f32")).to(device)

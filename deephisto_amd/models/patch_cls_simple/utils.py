@@ -21,3 +21,13 @@ def get_device():
     else:
         device = torch.device("cpu")
     return device
+
+
+def get_img_ano_paths(ds_folder, sample: str = "train"):
+    """(image, annotation) path pairs of a dataset folder: `images/<sample>/*.psi` with
+    `annotations/<sample>/<stem>.json` (the reference's top-level utils.py:4-14)."""
+    from pathlib import Path
+
+    ds_folder = Path(ds_folder)
+    img_paths = [p for p in (ds_folder / "images" / sample).iterdir() if p.is_file() and p.suffix == ".psi"]
+    return [(p, ds_folder / "annotations" / sample / f"{p.stem}.json") for p in img_paths]

@@ -7,22 +7,32 @@ yields, from `torch_generator` (region_samplers.py:641-738):
     features float32[B, P, P, 3] = uint8 / 255  (then `transforms(features)`),
     labels   int64[B]   (index of the class in the sorted class list),
     coords   float32[B, 2] = (pos_y, pos_x).
-That OUTPUT CONTRACT is the hot-path boundary and is kept here; the
-polygon geometry (shapely, absent) is out of scope this round, so regions are axis-aligned
-rectangles, for which the overlap constraint is closed form.  Origins are drawn on the host
-with a seeded NumPy generator; pixels never leave HBM: batches are cut, normalised (k/255),
-laid out and flipped by `dh_tile_gather` / `dh_tile_gather_aug`.
+That OUTPUT CONTRACT is the hot-path boundary.  Two producers keep it:
+
+* `RectRegionRndSampler` (synthetic data, BASELINE configs[1]): axis-aligned rectangles, for which the
+  overlap constraint is closed form; origins from a seeded NumPy generator;
+* `AnnoRegionRndSampler` / `AnnoRegionDenseSampler` / `RegionAnnotation` (second half of this file;
+  SURVEY section 8f row 2): the reference's polygon annotations, weights and random stream, with the
+  shapely geometry restated in `polygon.py`.
+
+In both, pixels never leave HBM: batches are cut, normalised (k/255), laid out and flipped by
+`dh_tile_gather` / `dh_tile_gather_aug`.
 """
 from __future__ import annotations
 
+import json
+from collections import defaultdict
 from dataclasses import dataclass
+from pathlib import Path
 from typing import Callable, Iterator, Sequence
 
 import numpy as np
 import torch
 
+from . import polygon as _pg
 from .. import tiles
 from .._lib import DH_LAYOUT_NCHW, DH_LAYOUT_NHWC
+from ..psimage_compat import Patch, open_slide
 
 
 @dataclass
@@ -146,3 +156,331 @@ def synthetic_regions(h: int, w: int, n_classes: int = 5, per_class: int = 6, mi
             x0 = int(rng.integers(0, w - ww + 1))
             out.append(RectRegion(name, y0, x0, y0 + hh, x0 + ww))
     return out
+
+
+# ======================================================================================================
+# Polygon annotations: RegionAnnotation / AnnoRegionRndSampler / AnnoRegionDenseSampler
+# (patch_samplers/region_samplers.py:19-871 of the reference)
+# ======================================================================================================
+# Host producers with the reference's constructor arguments, attributes, weights and -- where the
+# reference draws random numbers -- the same calls to the GLOBAL NumPy RNG in the same order.  The
+# geometry that the reference takes from shapely is restated in `polygon.py` (parity unpinned: no
+# fixture exists and shapely is absent).  What moves to the GPU is, as everywhere in this package,
+# the pixel work: slides are resident in HBM and batches are cut / normalised / laid out / flipped by
+# the gather kernels; there are no reader worker processes (`batches_per_worker` / `max_workers` only
+# shape the chunking of the random stream, as in the reference).
+class RegionAnnotation:
+    """One annotated polygon (region_samplers.py:19-191).  `vertices` are float64[N, 2] (x, y) in layer-1
+    coordinates; `polygon` holds the counter-clockwise ring at the sampler's layer scale."""
+
+    def __init__(self, img_path, region_idx: int, class_: str, vertices: np.ndarray, layer: int,
+                 layer_size: tuple[int, int]):
+        self.file_path = img_path
+        self.region_idx = region_idx
+        self.class_ = class_
+        self.vertices = vertices
+        self._layer = layer
+        self._layer_size = layer_size
+        if len(vertices.shape) != 2 or vertices.shape[1] != 2:
+            raise RuntimeError("Invalid region shape. It should be (N, 2).")
+        if vertices.dtype != np.float64:
+            raise RuntimeError("Invalid region dtype. It should be float64.")
+        ring = _pg.as_ccw(vertices if layer == 1 else vertices.copy() / layer)
+        if not _pg.is_simple(ring) or _pg.area(ring) == 0.0:
+            # the reference repairs such rings with shapely's buffer(0) (:68-70); without shapely the region
+            # is rejected here and counted by _parse_annotations as failed, like any other bad region
+            raise RuntimeError("Invalid (self-intersecting or degenerate) polygon.")
+        self.polygon = ring
+        self.area = _pg.area(ring)
+        self.bounds = _pg.bounds(ring)   # (minx, miny, maxx, maxy), shapely's order
+
+    def __str__(self) -> str:
+        stem = Path(self.file_path).stem if isinstance(self.file_path, (str, Path)) else "array"
+        return f"Region [{stem}, {self.region_idx}, {self.class_}, {self.vertices.shape}, {round(self.area, 0)}]"
+
+    def _extract_patch_coords_rnd(self, patch_size: int, n_patches: int, region_intersection: float = 0.75,
+                                  miss_limit: int = 500) -> list[tuple[int, int]]:
+        """Random (y, x) origins whose patch overlaps the polygon by more than `region_intersection` of its
+        area -- region_samplers.py:82-143: one `np.random.randint` for x, then one for y, per attempt."""
+        ps = patch_size
+        h, w = self._layer_size
+        x0, y0, x1, y1 = self.bounds
+        if self.area < ps * ps * region_intersection:
+            raise RuntimeError("Region is too small.")
+        coords = []
+        for _ in range(n_patches):
+            n_miss = 0
+            while n_miss < miss_limit:
+                x = np.random.randint(x0, min(max(x0 + 1, x1 - ps), w))
+                y = np.random.randint(y0, min(max(y0 + 1, y1 - ps), h))
+                if float(_pg.overlap_area_square(self.polygon, x, y, ps)) > ps * ps * region_intersection:
+                    coords.append((y, x))
+                    break
+                n_miss += 1
+            if n_miss >= miss_limit:
+                raise RuntimeError("Miss limit reached. Probably region is too small.")
+        return coords
+
+    def _extract_patch_coords_dense(self, patch_size: int, stride: int, region_intersection: float = 0.75
+                                    ) -> list[tuple[int, int]]:
+        """Grid origins inside the bounding box with enough overlap (region_samplers.py:145-191), row-major."""
+        h, w = self._layer_size
+        x0, y0, x1, y1 = (round(v) for v in self.bounds)
+        x1, y1 = min(x1, w - patch_size), min(y1, h - patch_size)
+        ys, xs = np.arange(y0, y1, stride), np.arange(x0, x1, stride)
+        if len(ys) == 0 or len(xs) == 0:
+            return []
+        yy, xx = np.meshgrid(ys, xs, indexing="ij")
+        ia = _pg.overlap_area_square(self.polygon, xx.ravel(), yy.ravel(), patch_size)
+        keep = ia > patch_size * patch_size * region_intersection
+        return [(int(y), int(x)) for y, x in zip(yy.ravel()[keep], xx.ravel()[keep])]
+
+
+def _load_annotation(anno):
+    if isinstance(anno, (str, Path)):
+        with open(anno) as f:
+            return json.load(f)
+    return anno   # already the list of {"class": ..., "vertices": [[x, y], ...]} records
+
+
+def _parse_annotations(img_anno_paths, layer: int, classes: list[str] | None = None):
+    """region_samplers.py:194-249: (regions of every class over all images, the same per image)."""
+    regions_all = defaultdict(list)
+    regions_per_image = [defaultdict(list) for _ in img_anno_paths]
+    regions_failed = 0
+    for j, (img, anno) in enumerate(img_anno_paths):
+        with open_slide(img) as psim:
+            size = psim.layer_size(layer)
+        for i, a in enumerate(_load_annotation(anno)):
+            cls = a["class"]
+            if classes is not None and cls not in classes:
+                continue
+            try:
+                reg = RegionAnnotation(img_path=img, region_idx=i, class_=cls,
+                                       vertices=np.array(a["vertices"], dtype=np.float64), layer=layer, layer_size=size)
+                reg.image_index = j
+                regions_per_image[j][cls].append(reg)
+                regions_all[cls].append(reg)
+            except Exception:
+                regions_failed += 1
+    if regions_failed > 0:
+        print(f"Failed to parse {regions_failed} regions.")
+    print(f"regions all: { {cls: len(r) for cls, r in regions_all.items()} }")
+    return regions_all, regions_per_image
+
+
+class _SlideBank:
+    """The images of a sampler: PSImage-like host readers + their layers resident in HBM (uploaded on first use)."""
+
+    def __init__(self, sources, layer: int, device):
+        self._readers = [open_slide(s) if not isinstance(s, torch.Tensor) else None for s in sources]
+        self._dev = [s.to(device).contiguous() if isinstance(s, torch.Tensor) else None for s in sources]
+        self.layer, self.device = layer, torch.device(device)
+
+    def host_patch(self, j: int, y: int, x: int, ps: int):
+        if self._readers[j] is None:
+            return self._dev[j][y:y + ps, x:x + ps, :].cpu().numpy()
+        return self._readers[j].get_region_from_layer(self.layer, (y, x), (y + ps, x + ps))
+
+    def slide(self, j: int) -> torch.Tensor:
+        if self._dev[j] is None:
+            r = self._readers[j]
+            h, w = r.layer_size(self.layer)
+            self._dev[j] = torch.from_numpy(np.ascontiguousarray(r.get_region_from_layer(self.layer, (0, 0), (h, w)))).to(self.device)
+        return self._dev[j]
+
+
+class AnnoRegionRndSampler:
+    """Area-weighted random patches from annotated polygons -- drop-in for region_samplers.py:252-796.
+
+    `img_anno_paths` pairs an image (path to a psimage file when that package is installed, a uint8[h,w,3]
+    array / GPU tensor, or any PSImage-like reader) with its annotation (path to the JSON list of
+    `{"class", "vertices"}` records, or that list)."""
+
+    def __init__(self, img_anno_paths, layer: int, patch_size: int, region_intersection: float = 0.75,
+                 patches_from_one_region: int = 4, region_area_influence: float = 0.5, classes: list[str] = None,
+                 one_image_for_batch: bool = False, device="cuda"):
+        self.img_anno_paths = img_anno_paths
+        self.layer = layer
+        self.patch_size = patch_size
+        self.region_intersection = region_intersection
+        self.patches_from_one_region = patches_from_one_region
+        self.region_area_influence = region_area_influence
+        self.one_image_for_batch = one_image_for_batch
+        self.regions, self.regions_per_image = _parse_annotations(img_anno_paths, layer=layer, classes=classes)
+        self.classes = sorted(list(self.regions.keys()))
+        if not self.classes:
+            raise ValueError("no usable annotated regions")
+        self._reg_w_all, self._reg_w_per_img, self._img_w, self._img_w_all = self._calc_weights(
+            self.regions, self.regions_per_image)
+        self._bank = _SlideBank([p[0] for p in img_anno_paths], layer, device)
+
+    # ---- weights (region_samplers.py:339-482) ------------------------------------------------------------
+    def _calc_area_weights(self, areas, area_influence: float):
+        assert -1 <= area_influence <= 1
+        areas_inv = [1 / a for a in areas]
+        w_proportional = np.array(areas) / sum(areas)
+        w_inv_proportional = np.array(areas_inv) / sum(areas_inv)
+        w_default = np.ones(len(areas), dtype=np.float64) / len(areas)
+        if area_influence == 0:
+            return w_default
+        if area_influence > 0:
+            w = w_default + (w_proportional - w_default) * area_influence
+        else:
+            w = w_default + (w_inv_proportional - w_default) * (-area_influence)
+        return w / sum(w)
+
+    def _calc_weights(self, regions, regions_per_image):
+        infl = self.region_area_influence
+        reg_weights_all = {cls: self._calc_area_weights([r.area for r in reg], infl) for cls, reg in regions.items()}
+        reg_weights_per_img = [{cls: self._calc_area_weights([r.area for r in reg], infl) for cls, reg in rpi.items()}
+                               for rpi in regions_per_image]
+        img_weights = {}
+        for cls in self.classes:
+            a = np.array([sum(r.area for r in (rpi[cls] if cls in rpi else [])) for rpi in regions_per_image])
+            img_weights[cls] = a / np.sum(a)
+        all_areas = [sum(sum(j.area for j in i) for i in rpi.values()) for rpi in regions_per_image]
+        img_weights_all = self._calc_area_weights(all_areas, infl)
+        return reg_weights_all, reg_weights_per_img, img_weights, img_weights_all
+
+    def __len__(self):   # region_samplers.py:788-796
+        ps = self.patch_size * self.layer
+        return int(sum(sum(r.area for r in lst) for lst in self.regions.values()) / (ps * ps))
+
+    # ---- the random stream (region_samplers.py:525-591) --------------------------------------------------
+    def _records(self, n: int, cls_idx: int = None) -> list[tuple[int, int, int, int]]:
+        """n (image index, y, x, class index) records, drawn like `_gen_single_proc`: class, region
+        (weighted), then `patches_from_one_region` origins from that region; a region that cannot deliver
+        (too small, miss limit) is skipped and another draw made, as the reference's `except: continue`."""
+        res = []
+        if self.one_image_for_batch:
+            img_idx = int(np.random.choice(len(self.img_anno_paths), p=self._img_w_all))
+            classes_for_img = self._reg_w_per_img[img_idx].keys()
+            classes_idx = [self.classes.index(cls) for cls in classes_for_img]
+        while len(res) < n:
+            try:
+                if self.one_image_for_batch:
+                    c_idx = cls_idx or np.random.choice(classes_idx)          # `or`: class 0 cannot be forced (reference, :552)
+                    cls = self.classes[c_idx]
+                    if cls not in classes_for_img:
+                        raise RuntimeError(f"Class {cls} not found in image")
+                    regs, w = self.regions_per_image[img_idx][cls], self._reg_w_per_img[img_idx][cls]
+                else:
+                    c_idx = cls_idx or np.random.randint(len(self.classes))  # same `or` (:572)
+                    cls = self.classes[c_idx]
+                    regs, w = self.regions[cls], self._reg_w_all[cls]
+                region = regs[int(np.random.choice(len(regs), p=w))]
+                k = min(self.patches_from_one_region, n - len(res))
+                coords = region._extract_patch_coords_rnd(n_patches=k, patch_size=self.patch_size,
+                                                          region_intersection=self.region_intersection)
+                res.extend((region.image_index, int(y), int(x), int(c_idx)) for y, x in coords)
+            except RuntimeError:
+                continue
+        return res
+
+    def _split_chunks(self, n, k):
+        q = [k] * (n // k)
+        if n % k > 0:
+            q.append(n % k)
+        return q
+
+    def _gen_single_proc(self, n: int, cls_idx: int = None) -> list[tuple[Patch, int]]:
+        ps = self.patch_size
+        return [(Patch(self.layer, pos_x=x, pos_y=y, patch_size=ps, data=self._bank.host_patch(j, y, x, ps)), c)
+                for j, y, x, c in self._records(n, cls_idx)]
+
+    def structs_generator(self, batch_size: int, n_batches: int, batches_per_worker: int = 2, max_workers: int = None,
+                          cls_idx: int = None) -> Iterator[list[tuple[Patch, int]]]:
+        """Lists of `batch_size` (Patch, class index) pairs (region_samplers.py:641-683)."""
+        for i in self._split_chunks(n_batches, batches_per_worker):
+            lst = self._gen_single_proc(batch_size * i, cls_idx)
+            for k in range(0, len(lst), batch_size):
+                yield lst[k:k + batch_size]
+
+    # ---- device batches --------------------------------------------------------------------------------
+    def _assemble(self, recs, layout: int, dtype, flip_h: bool = False, flip_v: bool = False):
+        """Cut the records' patches from the HBM-resident slides into one batch tensor (+ labels, coords)."""
+        dev, ps = self._bank.device, self.patch_size
+        arr = np.array(recs, dtype=np.int64).reshape(-1, 4)
+        out = None
+        for j in np.unique(arr[:, 0]):
+            sel = np.nonzero(arr[:, 0] == j)[0]
+            o_dev = torch.from_numpy(arr[sel, 1:3].astype(np.int32)).to(dev)
+            part = tiles.gather_tiles_aug(self._bank.slide(int(j)), o_dev, ps, layout, dtype, flip_h, flip_v)
+            if len(sel) == len(arr):
+                out = part
+            else:
+                if out is None:
+                    out = torch.empty((len(arr),) + tuple(part.shape[1:]), dtype=part.dtype, device=dev)
+                out[torch.from_numpy(sel).to(dev)] = part
+        labels = torch.from_numpy(arr[:, 3].copy()).to(dev)
+        coords = torch.from_numpy(arr[:, 1:3].astype(np.float32)).to(dev)
+        return out, labels, coords
+
+    def torch_generator(self, batch_size: int, n_batches: int, batches_per_worker: int = 2,
+                        transforms: Callable | None = None, max_workers: int = None, cls_idx: int = None
+                        ) -> Iterator[tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """(features f32[B,P,P,3] = uint8/255, labels int64[B], coords f32[B,2] (y, x)) on the GPU, then
+        `transforms(features)` -- region_samplers.py:685-738.  As in the reference, `cls_idx` is accepted but
+        not forwarded (`_gen_single_proc_torch(n)`, :725), and one chunk of `batches_per_worker` batches is one
+        run of the random stream (so `one_image_for_batch` picks its image once per chunk)."""
+        for i in self._split_chunks(n_batches, batches_per_worker):
+            recs = self._records(batch_size * i)
+            for k in range(0, len(recs), batch_size):
+                features, labels, coords = self._assemble(recs[k:k + batch_size], DH_LAYOUT_NHWC, torch.float32)
+                if transforms is not None:
+                    features = transforms(features)
+                yield features, labels, coords
+
+    def device_batches(self, batch_size: int, n_batches: int, flips: bool = True, dtype=torch.float32,
+                       batches_per_worker: int = 2) -> Iterator[tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """Training fast path: [B,3,P,P] batches with train.py:69-81's permute + RandomHorizontalFlip +
+        RandomVerticalFlip (one torch coin each per batch, in that order) fused into the gather kernel."""
+        for i in self._split_chunks(n_batches, batches_per_worker):
+            recs = self._records(batch_size * i)
+            for k in range(0, len(recs), batch_size):
+                fh = bool(flips and torch.rand(1).item() < 0.5)
+                fv = bool(flips and torch.rand(1).item() < 0.5)
+                yield self._assemble(recs[k:k + batch_size], DH_LAYOUT_NCHW, dtype, fh, fv)
+
+
+class AnnoRegionDenseSampler:
+    """Every grid patch of every annotated region, class by class (region_samplers.py:799-871)."""
+
+    def __init__(self, img_anno_paths, layer: int, patch_size: int, stride: int, region_intersection: float = 0.75,
+                 classes: list[str] = None, device="cuda"):
+        self.img_anno_paths = img_anno_paths
+        self.layer = layer
+        self.patch_size = patch_size
+        self.stride = stride
+        self.region_intersection = region_intersection
+        self.regions, _ = _parse_annotations(img_anno_paths, layer=layer, classes=classes)
+        self.classes = sorted(list(self.regions.keys()))
+        self._bank = _SlideBank([p[0] for p in img_anno_paths], layer, device)
+
+    def _patches_one_region(self, region: RegionAnnotation) -> list[Patch]:
+        ps = self.patch_size
+        coords = region._extract_patch_coords_dense(patch_size=ps, stride=self.stride,
+                                                    region_intersection=self.region_intersection)
+        return [Patch(self.layer, pos_x=c[1], pos_y=c[0], patch_size=ps,
+                      data=self._bank.host_patch(region.image_index, c[0], c[1], ps)) for c in coords]
+
+    def structs_generator(self) -> Iterator[tuple[Patch, int]]:
+        for cls_idx, cls in enumerate(self.classes):
+            for region in self.regions[cls]:
+                for p in self._patches_one_region(region):
+                    yield p, cls_idx
+
+    def device_batches(self, batch_size: int, layout: int = DH_LAYOUT_NCHW, dtype=torch.float32
+                       ) -> Iterator[tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """The same patches in the same order as device tensors (tiles cut on the GPU), `batch_size` at a time."""
+        dev, ps = self._bank.device, self.patch_size
+        for cls_idx, cls in enumerate(self.classes):
+            for region in self.regions[cls]:
+                coords = region._extract_patch_coords_dense(patch_size=ps, stride=self.stride,
+                                                            region_intersection=self.region_intersection)
+                for k in range(0, len(coords), batch_size):
+                    o = np.array(coords[k:k + batch_size], dtype=np.int32)
+                    o_dev = torch.from_numpy(o).to(dev)
+                    x = tiles.gather_tiles(self._bank.slide(region.image_index), o_dev, ps, layout, dtype, check_bounds=False)
+                    yield x, torch.full((len(o),), cls_idx, dtype=torch.int64, device=dev), tiles.tile_coords(o_dev)

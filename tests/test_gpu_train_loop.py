@@ -97,3 +97,54 @@ def test_train_mirror_runs_and_learns(dev, tmp_path):
     model.load_state_dict(ck)          # the checkpoint is the BEST epoch, the returned model the last one
     got = model.eval()(x.to(dev)).cpu()
     assert float((got - want).abs().max()) <= 2e-4
+
+
+def test_anno_region_sampler_device_batches(dev):
+    """AnnoRegionRndSampler (polygon annotations, two images): torch_generator keeps the reference's output
+    contract bit-exactly (uint8/255 in float32), device_batches = permute + batch-level flips, and the fused
+    train step runs on its batches."""
+    from deephisto_amd.patch_samplers.region_samplers import AnnoRegionRndSampler
+    rng = np.random.default_rng(0)
+    img0 = synth.synth_slide(1500, 1800, 3)
+    img1 = synth.synth_slide(1400, 1300, 4)
+    ang = np.sort(rng.uniform(0, 2 * np.pi, 15))
+    star = np.stack([800 + rng.uniform(300, 600, 15) * np.cos(ang), 750 + rng.uniform(300, 600, 15) * np.sin(ang)], 1)
+    a0 = [{"class": "TUM", "vertices": star.tolist()}, {"class": "BG", "vertices": [[50, 50], [700, 60], [680, 700], [40, 650]]}]
+    a1 = [{"class": "LP", "vertices": [[100, 100], [1200, 150], [1100, 1300], [150, 1200]]}]
+    smp = AnnoRegionRndSampler([(img0, a0), (img1, a1)], layer=1, patch_size=96, patches_from_one_region=4, device=dev)
+    imgs = [img0, img1]
+    np.random.seed(21)
+    recs = smp._records(2 * 8)
+    np.random.seed(21)
+    out = list(smp.torch_generator(batch_size=8, n_batches=2))
+    assert len(out) == 2
+    for b, (f, lab, c) in enumerate(out):
+        assert f.dtype == torch.float32 and tuple(f.shape) == (8, 96, 96, 3) and f.device.type == "cuda"
+        assert lab.dtype == torch.int64 and c.dtype == torch.float32 and tuple(c.shape) == (8, 2)
+        for i, (j, y, x, cls) in enumerate(recs[8 * b:8 * b + 8]):
+            want = imgs[j][y:y + 96, x:x + 96].astype(np.float32) / 255
+            np.testing.assert_array_equal(f[i].cpu().numpy(), want)
+            assert int(lab[i]) == cls and c[i].tolist() == [float(y), float(x)]
+    # device_batches: NCHW + the two torch coins per batch (horizontal first)
+    np.random.seed(22); torch.manual_seed(5)
+    recs = smp._records(8)
+    np.random.seed(22); torch.manual_seed(5)
+    fh = torch.rand(1).item() < 0.5
+    fv = torch.rand(1).item() < 0.5
+    torch.manual_seed(5)
+    x, lab, c = next(smp.device_batches(8, 1))
+    assert tuple(x.shape) == (8, 3, 96, 96)
+    for i, (j, y, xx, cls) in enumerate(recs):
+        want = torch.from_numpy(imgs[j][y:y + 96, xx:xx + 96].astype(np.float32) / 255).permute(2, 0, 1)
+        if fh: want = torch.flip(want, dims=[2])
+        if fv: want = torch.flip(want, dims=[1])
+        assert torch.equal(x[i].cpu(), want)
+    # and the training step consumes it
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    torch.manual_seed(0)
+    model = get_model(3, "f32").to(dev).train()
+    losses = []
+    for xb, yb, _ in smp.device_batches(8, 6):
+        loss, _ = model.train_step(xb, yb, lr=1e-3)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
