@@ -36,6 +36,8 @@ SIGNATURES = {
     "dh_tile_coords_f32": (C.c_int, [_p, _i64, _p, _p]),
     "dh_accumulate_logits": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i64, _i64, _p, _p, _p]),
     "dh_argmax_map": (C.c_int, [_p, _i64, _i32, _p, _p]),
+    "dh_colorize_map": (C.c_int, [_p, _i64, _p, _i32, _p, _p]),
+    "dh_overlay_blend": (C.c_int, [_p, _p, _i64, C.c_double, _p, _p]),
     "dh_resnet18_create": (C.c_int, [C.POINTER(_p), _i32, _i32]),
     "dh_resnet18_destroy": (None, [_p]),
     "dh_resnet18_set_param": (C.c_int, [_p, C.c_char_p, _p, _i64]),

@@ -516,3 +516,44 @@ extern "C" int dh_accumulate_logits(const float* logits, const int32_t* yx_host,
   if (map) return dh_argmax_map(canvas, dh_ * dw_, n_cls, map, stream);
   return DH_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Visualisation of the class map (examples/predict_full_patched.py:81-113): HBM-bound byte work.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void colorize_kernel(const int64_t* __restrict__ map, int64_t n, const uint8_t* __restrict__ lut,
+                                                       int n_cls, uint8_t* __restrict__ rgb) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = map[i];
+    uint8_t r = 0, g = 0, b = 0;
+    if (c >= 0 && c < n_cls) { r = lut[3 * c]; g = lut[3 * c + 1]; b = lut[3 * c + 2]; }
+    rgb[3 * i] = r; rgb[3 * i + 1] = g; rgb[3 * i + 2] = b;
+  }
+}
+__global__ __launch_bounds__(256) void overlay_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ col, int64_t n,
+                                                      double alpha, uint8_t* __restrict__ out) {
+  const double beta = 1.0 - alpha;   // NumPy evaluates (1 - alpha) in float64 first
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (uint8_t)((double)img[i] * alpha + (double)col[i] * beta);   // values are in [0, 255]: the cast truncates
+}
+}  // namespace
+
+extern "C" int dh_colorize_map(const int64_t* map, int64_t n, const uint8_t* lut, int32_t n_cls, uint8_t* rgb, void* stream) {
+  DH_REQUIRE(n >= 0 && n_cls >= 0, "colorize: bad sizes");
+  if (n == 0) return DH_OK;
+  DH_REQUIRE(map && rgb && (lut || n_cls == 0), "colorize: null pointer");
+  hipLaunchKernelGGL(colorize_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)), dim3(256), 0, dh::as_stream(stream),
+                     map, n, lut, n_cls, rgb);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+extern "C" int dh_overlay_blend(const uint8_t* img, const uint8_t* col, int64_t n, double alpha, uint8_t* out, void* stream) {
+  DH_REQUIRE(n >= 0 && alpha >= 0.0 && alpha <= 1.0, "overlay: bad arguments");
+  if (n == 0) return DH_OK;
+  DH_REQUIRE(img && col && out, "overlay: null pointer");
+  hipLaunchKernelGGL(overlay_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)), dim3(256), 0, dh::as_stream(stream),
+                     img, col, n, alpha, out);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}

@@ -211,3 +211,44 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     logits = torch.cat([logits_unique, logits_unique[-1:].expand(pad, -1)]) if pad else logits_unique
     _, cmap = tiles.accumulate_logits(logits.contiguous(), origins, P, downscale, sampler.h, sampler.w)
     return (cmap, logits) if return_logits else cmap
+
+
+def perform_and_save_visualizations(img, anno_dsc, pred, out_dir: Path = Path("."), stem: str | None = None,
+                                    alpha: float = 0.6, save: bool = True, device="cuda"):
+    """Colourised class mask, the slide at the map's resolution and their overlay -- predict_full_patched.py:81-113.
+
+    `img`: path (psimage, when installed: `get_region(..., target_hw)` as the reference) or a uint8[H,W,3]
+    array / GPU tensor, which is sampled at the map's resolution by nearest source pixel (psimage's own
+    resampler is third-party and unknown here).  The colour lookup and the float64 blend run on the GPU
+    (`dh_colorize_map`, `dh_overlay_blend`) and are bit-identical to the reference's NumPy lines.
+    Returns (mask, image, overlay) as uint8[h, w, 3] NumPy arrays; JPEGs are written when `save`."""
+    dev = torch.device(device)
+    pred_t = pred if isinstance(pred, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pred))
+    pred_t = pred_t.to(dev, torch.int64).contiguous()
+    h, w = int(pred_t.shape[0]), int(pred_t.shape[1])
+    n_ids = max((a.id for a in anno_dsc.anno_classes), default=-1) + 1
+    lut = torch.zeros((n_ids, 3), dtype=torch.uint8)
+    for a in anno_dsc.anno_classes:
+        lut[a.id] = torch.tensor(a.color, dtype=torch.uint8)
+    colored = tiles.colorize_map(pred_t, lut)
+    if isinstance(img, (str, Path)):
+        stem = stem or Path(img).stem
+        with open_slide(img) as psim:
+            small = torch.from_numpy(np.ascontiguousarray(psim.get_region((0, 0), (psim.height, psim.width), target_hw=(h, w)))).to(dev)
+    else:
+        full = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
+        full = full.to(dev)
+        ys = (torch.arange(h, device=dev) * full.shape[0]) // h
+        xs = (torch.arange(w, device=dev) * full.shape[1]) // w
+        small = full[ys][:, xs].contiguous()
+    overlay = tiles.overlay_blend(small, colored, alpha)
+    mask_np, img_np, ov_np = colored.cpu().numpy(), small.cpu().numpy(), overlay.cpu().numpy()
+    if save:
+        from PIL import Image
+        out_dir = Path(out_dir)
+        out_dir.mkdir(exist_ok=True, parents=True)
+        stem = stem or "slide"
+        Image.fromarray(mask_np).save(out_dir / f"{stem}_mask.jpg", quality=95)
+        Image.fromarray(img_np).save(out_dir / f"{stem}.jpg", quality=95)
+        Image.fromarray(ov_np).save(out_dir / f"{stem}_overlay.jpg", quality=95)
+    return mask_np, img_np, ov_np

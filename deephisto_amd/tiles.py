@@ -140,3 +140,29 @@ def accumulate_logits(logits: torch.Tensor, origins_host: np.ndarray, patch: int
                                      cmap.data_ptr() if cmap is not None else None,
                                      _stream(logits.device)), "dh_accumulate_logits")
     return canvas, cmap
+
+
+def colorize_map(class_map: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
+    """uint8[h, w, 3]: `colored[pred == id] = color` for every class (predict_full_patched.py:89-95);
+    `lut` = uint8[n_cls, 3] indexed by class id, ids without an entry stay black."""
+    _require_cuda(class_map, "class_map")
+    if class_map.dtype != torch.int64 or not class_map.is_contiguous():
+        raise ValueError("class_map must be contiguous int64")
+    lut = lut.to(device=class_map.device, dtype=torch.uint8).contiguous()
+    out = torch.empty(tuple(class_map.shape) + (3,), dtype=torch.uint8, device=class_map.device)
+    check(lib().dh_colorize_map(class_map.data_ptr(), class_map.numel(), lut.data_ptr(), int(lut.shape[0]), out.data_ptr(),
+                                _stream(class_map.device)), "dh_colorize_map")
+    return out
+
+
+def overlay_blend(img: torch.Tensor, colored: torch.Tensor, alpha: float = 0.6) -> torch.Tensor:
+    """`(img * alpha + colored * (1 - alpha)).astype(uint8)` (predict_full_patched.py:108-110), float64 math."""
+    _require_cuda(img, "img")
+    _require_cuda(colored, "colored")
+    if img.dtype != torch.uint8 or colored.dtype != torch.uint8 or img.shape != colored.shape:
+        raise ValueError("img and colored must be uint8 tensors of one shape")
+    img, colored = img.contiguous(), colored.contiguous()
+    out = torch.empty_like(img)
+    check(lib().dh_overlay_blend(img.data_ptr(), colored.data_ptr(), img.numel(), float(alpha), out.data_ptr(),
+                                 _stream(img.device)), "dh_overlay_blend")
+    return out

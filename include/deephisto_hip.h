@@ -109,6 +109,16 @@ int dh_accumulate_logits(const float* logits_dev, const int32_t* yx_host, int64_
 int dh_argmax_map(const float* canvas_dev, int64_t n_cells, int32_t n_cls, int64_t* map_dev,
                   void* stream);
 
+/* ---- visualisation of the class map (examples/predict_full_patched.py:81-113) ----
+ * dh_colorize_map: `colored[pred == anno.id] = anno.color` for every class (:93-95):
+ *   rgb[i] = lut[map[i]] when 0 <= map[i] < n_cls, else (0,0,0); lut = uint8[n_cls][3] on the device.
+ * dh_overlay_blend: `(img * alpha + colored * (1 - alpha)).astype(np.uint8)` (:109-110) in float64,
+ *   truncating like NumPy's cast; n_bytes = h*w*3. */
+int dh_colorize_map(const int64_t* map_dev, int64_t n_cells, const uint8_t* lut_dev, int32_t n_cls,
+                    uint8_t* rgb_dev, void* stream);
+int dh_overlay_blend(const uint8_t* img_dev, const uint8_t* colored_dev, int64_t n_bytes, double alpha,
+                     uint8_t* out_dev, void* stream);
+
 /* ---- a6: ResNet-18 patch classifier forward ---------------------------------
  * Replaces `model(features)` for the network built by get_model
  * (models/patch_cls_simple/model.py:5-11: torchvision resnet18 + fc[n_cls,512])

@@ -81,3 +81,31 @@ def test_foreign_patches_and_foreign_model(dev):
     with torch.no_grad():
         want = net(x).cpu().numpy()
     assert np.abs(got - want).max() <= 1e-6
+
+
+def test_visualisation_matches_numpy(dev, tmp_path):
+    """Colourised mask and overlay (predict_full_patched.py:88-110) bit-exact with the NumPy lines."""
+    from deephisto_amd.anno.utils import AnnoDescription
+    from deephisto_amd.examples.predict_full_patched import perform_and_save_visualizations
+    from oracle import visualize
+    anno = AnnoDescription.with_known_colors({"AT": (245, 119, 34), "BG": (153, 255, 255), "LP": (64, 170, 72),
+                                              "MM": (255, 0, 0), "TUM": (33, 67, 156)})
+    assert [a.id for a in anno.anno_classes] == [0, 1, 2, 3, 4] and anno.color_by_label("LP") == (64, 170, 72)
+    rng = np.random.default_rng(0)
+    pred = rng.integers(0, 6, size=(61, 83)).astype(np.int64)        # id 5 has no colour: stays black
+    slide = synth.synth_slide(61 * 16 + 5, 83 * 16 + 9, 2)
+    mask, img, ov = perform_and_save_visualizations(slide, anno, pred, out_dir=tmp_path, stem="t", device=dev)
+    want_mask = visualize.colorize(pred, {a.id: a.color for a in anno.anno_classes})
+    np.testing.assert_array_equal(mask, want_mask)
+    ys = (np.arange(61) * slide.shape[0]) // 61
+    xs = (np.arange(83) * slide.shape[1]) // 83
+    np.testing.assert_array_equal(img, slide[ys][:, xs])
+    np.testing.assert_array_equal(ov, visualize.overlay(img, want_mask, 0.6))
+    assert (tmp_path / "t_mask.jpg").exists() and (tmp_path / "t.jpg").exists() and (tmp_path / "t_overlay.jpg").exists()
+    # every byte pair through the blend
+    from deephisto_amd import tiles
+    a = torch.arange(256, dtype=torch.uint8).repeat_interleave(256).reshape(256, 256, 1).expand(256, 256, 3).contiguous()
+    b = torch.arange(256, dtype=torch.uint8).repeat(256).reshape(256, 256, 1).expand(256, 256, 3).contiguous()
+    for alpha in (0.6, 0.25, 1.0, 0.0):
+        got = tiles.overlay_blend(a.to(dev), b.to(dev), alpha).cpu().numpy()
+        np.testing.assert_array_equal(got, visualize.overlay(a.numpy(), b.numpy(), alpha))
