@@ -176,8 +176,9 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     """
     import torch.distributed as dist
 
-    slide = sampler.data_device
-    dev = slide.device
+    streamed = not sampler.resident          # ONDISK_MULTIPROC: row strips are uploaded as they are needed
+    slide = None if streamed else sampler.data_device
+    dev = sampler.device if streamed else slide.device
     P = sampler.patch_size
     origins = sampler.origins                      # padded, reference order
     n_unique, n_padded = sampler.n_tiles, len(origins)
@@ -198,7 +199,9 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     for st in lanes[1:]:
         st.wait_stream(main)
     fwd = lib().dh_resnet18_forward_tiles
-    for k, s in enumerate(range(0, hi - lo, mb)):
+    if streamed:
+        _forward_streamed(sampler, handles[0], origins[lo:hi], local, n_classes, mb)
+    for k, s in enumerate(range(0, 0 if streamed else hi - lo, mb)):
         e = min(s + mb, hi - lo)
         lane = k % len(handles)
         check(fwd(handles[lane], slide.data_ptr(), sampler.h, sampler.w, o_dev.data_ptr() + 8 * s, e - s, P,
@@ -211,6 +214,52 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     logits = torch.cat([logits_unique, logits_unique[-1:].expand(pad, -1)]) if pad else logits_unique
     _, cmap = tiles.accumulate_logits(logits.contiguous(), origins, P, downscale, sampler.h, sampler.w)
     return (cmap, logits) if return_logits else cmap
+
+
+def _forward_streamed(sampler, handle, origins: np.ndarray, local: torch.Tensor, n_classes: int, micro_batch: int):
+    """Logits of `origins` (this rank's range, reference order) when the slide is not resident: the tiles are
+    grouped by tile row; the P-row strip of each group is read from the reader into a pinned buffer, uploaded
+    on a side stream (two strip buffers: the upload of strip k+1 runs under the forward of strip k) and
+    serves as the 'slide' of dh_resnet18_forward_tiles; logits land at their reference-order positions."""
+    dev, P, w = sampler.device, sampler.patch_size, sampler.w
+    main = torch.cuda.current_stream(dev)
+    copy_stream = torch.cuda.Stream(dev)
+    ys = np.unique(origins[:, 0])
+    groups = [np.nonzero(origins[:, 0] == y)[0] for y in ys]
+    pinned = [torch.empty((P, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    strip = [torch.empty((P, w, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    uploaded = [torch.cuda.Event() for _ in range(2)]
+    consumed = [None, None]
+    fwd = lib().dh_resnet18_forward_tiles
+
+    def stage(k):
+        b = k & 1
+        if consumed[b] is not None:
+            consumed[b].synchronize()
+        y = int(ys[k])
+        np.copyto(pinned[b].numpy(), sampler.read_region(y, 0, y + P, w))
+        with torch.cuda.stream(copy_stream):
+            strip[b].copy_(pinned[b], non_blocking=True)
+            uploaded[b].record(copy_stream)
+
+    if len(ys):
+        stage(0)
+    for k, idx in enumerate(groups):
+        b = k & 1
+        main.wait_event(uploaded[b])
+        if k + 1 < len(ys):
+            stage(k + 1)
+        o = np.zeros((len(idx), 2), np.int32)
+        o[:, 1] = origins[idx, 1]
+        o_dev = torch.from_numpy(o).to(dev)
+        out = torch.empty((len(idx), n_classes), dtype=torch.float32, device=dev)
+        for s0 in range(0, len(idx), micro_batch):
+            e0 = min(s0 + micro_batch, len(idx))
+            check(fwd(handle, strip[b].data_ptr(), P, w, o_dev.data_ptr() + 8 * s0, e0 - s0, P,
+                      out.data_ptr() + 4 * n_classes * s0, C.c_void_p(main.cuda_stream)), "dh_resnet18_forward_tiles")
+        local[torch.from_numpy(idx).to(dev)] = out
+        consumed[b] = torch.cuda.Event()
+        consumed[b].record(main)
 
 
 def perform_and_save_visualizations(img, anno_dsc, pred, out_dir: Path = Path("."), stem: str | None = None,

@@ -17,7 +17,10 @@ Documented deviations from the reference:
   `stride=None` means `stride = patch_size` (the reference crashes);
   a slide smaller than the patch raises ValueError (the reference yields negative origins);
   `mode` defaults to INMEMORY_SINGLEPROC (predict_full_patched.py:165-167 omits it);
-  tensors from `generator_torch()` are on the sampler's device, not on the CPU.
+  tensors from `generator_torch()` are on the sampler's device, not on the CPU;
+  ONDISK_MULTIPROC keeps ONE reader open and reads patches / row strips on demand (pinned staging
+  buffers, upload on a side stream) instead of a pool of worker processes that re-open the file per
+  batch (:332-351, 406-423); read errors propagate instead of being printed and the batch dropped.
 """
 from __future__ import annotations
 
@@ -50,8 +53,8 @@ class DevicePatch(Patch):
 
     @property
     def data(self):
-        a = self._sampler.data
-        return a[self.pos_y:self.pos_y + self.patch_size, self.pos_x:self.pos_x + self.patch_size, :]
+        s, P = self._sampler, self.patch_size
+        return s.read_region(self.pos_y, self.pos_x, self.pos_y + P, self.pos_x + P)
 
     def __repr__(self):
         return f"DevicePatch(layer={self.layer}, pos_x={self.pos_x}, pos_y={self.pos_y}, patch_size={self.patch_size})"
@@ -76,21 +79,35 @@ class _SlideHolder:
                 self._dev, self.device = t.contiguous(), t.device
             else:
                 self._host = t.contiguous().numpy()
+        elif self.mode == SamplerExecutionMode.ONDISK_MULTIPROC:
+            # the layer stays where it is (full_samplers.py:332-351 re-opens the file per batch in worker
+            # processes); here ONE reader stays open and is read in patches / row strips on demand
+            self._reader = open_slide(psimage_path)
+            self._reader._assert_layer(layer)
+            self.h, self.w = self._reader.layer_size(self.layer)
         else:
             with open_slide(psimage_path) as psim:
                 psim._assert_layer(layer)
                 self.h, self.w = psim.layer_size(self.layer)
-                if self.mode == SamplerExecutionMode.INMEMORY_SINGLEPROC:
-                    self._host = np.ascontiguousarray(
-                        psim.get_region_from_layer(self.layer, (0, 0), (self.h, self.w)))
-        if mode == SamplerExecutionMode.ONDISK_MULTIPROC and self._host is None and self._dev is None:
-            raise NotImplementedError(
-                "ONDISK_MULTIPROC streaming from .psi files is not built yet (SURVEY section 8f row 3); "
-                "use INMEMORY_SINGLEPROC")
+                self._host = np.ascontiguousarray(
+                    psim.get_region_from_layer(self.layer, (0, 0), (self.h, self.w)))
+
+    @property
+    def resident(self) -> bool:
+        """False in ONDISK_MULTIPROC mode: pixels are streamed from the reader, never held whole."""
+        return getattr(self, "_reader", None) is None
+
+    def read_region(self, y0: int, x0: int, y1: int, x1: int) -> np.ndarray:
+        """uint8[y1-y0, x1-x0, 3] of the layer from wherever it lives (host array, reader, or HBM)."""
+        if getattr(self, "_reader", None) is not None:
+            return self._reader.get_region_from_layer(self.layer, (y0, x0), (y1, x1))
+        return self.data[y0:y1, x0:x1, :]
 
     @property
     def data(self) -> np.ndarray:
-        """uint8[h, w, 3] host array of the layer (reference attribute, :319-320)."""
+        """uint8[h, w, 3] host array of the layer (reference attribute, :319-320; absent in on-disk mode)."""
+        if not self.resident:
+            raise AttributeError("ONDISK_MULTIPROC holds no whole-layer array; use read_region()")
         if self._host is None:
             self._host = self._dev.cpu().numpy()
         return self._host
@@ -98,6 +115,8 @@ class _SlideHolder:
     @property
     def data_device(self) -> torch.Tensor:
         """uint8[h, w, 3] slide resident in HBM (uploaded once, on first use)."""
+        if not self.resident:
+            raise AttributeError("ONDISK_MULTIPROC streams the slide; nothing is resident in HBM")
         if self._dev is None:
             self._dev = torch.from_numpy(self._host).to(self.device)
         return self._dev
@@ -221,10 +240,51 @@ class FullImageDenseSampler(_SlideHolder):
             patches = [DevicePatch(self.layer, int(x), int(y), self.patch_size, self) for y, x in o[i]]
             yield patches, i / nb
 
+    def _staged_batches(self):
+        """On-disk mode: (uint8[B*P, P, 3] device staging image, int32[B,2] staging origins on the device,
+        batch index) -- the batch's patches are read from the reader into a pinned buffer and uploaded on a
+        side stream while the consumer works on the previous batch (two buffers)."""
+        nb, B, P = len(self), self.batch_size, self.patch_size
+        dev = self.device
+        o = self._origins.reshape(nb, B, 2)
+        pinned = [torch.empty((B * P, P, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        staged = [torch.empty((B * P, P, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]
+        consumed = [None, None]
+        copy_stream = torch.cuda.Stream(dev)
+        so = torch.stack([torch.arange(B, dtype=torch.int32) * P, torch.zeros(B, dtype=torch.int32)], 1).to(dev)
+
+        def stage(i):
+            k = i & 1
+            if consumed[k] is not None:
+                consumed[k].synchronize()        # the consumer's kernels on that buffer have finished
+            buf = pinned[k].numpy()
+            for j, (y, x) in enumerate(o[i]):
+                buf[j * P:(j + 1) * P] = self.read_region(int(y), int(x), int(y) + P, int(x) + P)
+            with torch.cuda.stream(copy_stream):
+                staged[k].copy_(pinned[k], non_blocking=True)
+                ready[k].record(copy_stream)
+
+        if nb:
+            stage(0)
+        for i in range(nb):
+            k = i & 1
+            torch.cuda.current_stream(dev).wait_event(ready[k])
+            if i + 1 < nb:
+                stage(i + 1)                     # read ahead into the other buffer while batch i is consumed
+            yield staged[k], so, i
+            consumed[k] = torch.cuda.Event()
+            consumed[k].record(torch.cuda.current_stream(dev))
+
     def generator_device(self, layout: int = DH_LAYOUT_NCHW, dtype=torch.float32
                          ) -> Iterator[tuple[torch.Tensor, np.ndarray, float]]:
         """(tiles on device in `layout`/`dtype`, int32[B,2] host origins, progress)."""
         nb = len(self)
+        if not self.resident:
+            o = self._origins.reshape(nb, self.batch_size, 2)
+            for img, so, i in self._staged_batches():
+                yield tiles.gather_tiles(img, so, self.patch_size, layout, dtype, check_bounds=False), o[i], i / nb
+            return
         slide = self.data_device
         o = self._origins.reshape(nb, self.batch_size, 2)
         o_dev = torch.from_numpy(self._origins).to(slide.device).reshape(nb, self.batch_size, 2)
@@ -235,6 +295,12 @@ class FullImageDenseSampler(_SlideHolder):
     def generator_torch(self) -> Iterator[tuple[torch.Tensor, torch.Tensor, float]]:
         """(features f32[B,P,P,3] in [0,1], coords f32[B,2] (y,x), progress) -- :437-452."""
         nb = len(self)
+        if not self.resident:
+            o_all = torch.from_numpy(self._origins).to(self.device).reshape(nb, self.batch_size, 2)
+            for img, so, i in self._staged_batches():
+                f = tiles.gather_tiles(img, so, self.patch_size, DH_LAYOUT_NHWC, torch.float32, check_bounds=False)
+                yield f, tiles.tile_coords(o_all[i].contiguous()), i / nb
+            return
         slide = self.data_device
         o_dev = torch.from_numpy(self._origins).to(slide.device).reshape(nb, self.batch_size, 2)
         for i in range(nb):

@@ -4,7 +4,8 @@ The reference reads slides through the third-party `psimage` package
 (`PSImage(path)`, `layer_size`, `get_region_from_layer`) and
 wraps tiles in `psimage.core.patches.Patch(layer, pos_x, pos_y, patch_size, data)`.
 `psimage` is used when it is importable; otherwise the same duck-typed protocol
-is served by in-memory arrays, so samplers accept either a path or an array.
+is served by in-memory arrays and by memory-mapped `.npy` files, so samplers accept a
+path, an array or a reader object.
 """
 from __future__ import annotations
 
@@ -63,6 +64,9 @@ def open_slide(source):
         return ArraySlide(source)
     if hasattr(source, "layer_size") and hasattr(source, "get_region_from_layer"):
         return source
+    if isinstance(source, (str, Path)) and Path(source).suffix == ".npy":
+        # a plain on-disk slide: uint8[h, w, 3] in NumPy's .npy container, memory-mapped (never read whole)
+        return ArraySlide(np.load(source, mmap_mode="r"))
     if isinstance(source, (str, Path)):
         try:
             from psimage.core.image import PSImage  # type: ignore

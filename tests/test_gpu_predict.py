@@ -109,3 +109,37 @@ def test_visualisation_matches_numpy(dev, tmp_path):
     for alpha in (0.6, 0.25, 1.0, 0.0):
         got = tiles.overlay_blend(a.to(dev), b.to(dev), alpha).cpu().numpy()
         np.testing.assert_array_equal(got, visualize.overlay(a.numpy(), b.numpy(), alpha))
+
+
+def test_ondisk_mode_streams_and_matches_resident(dev, tmp_path):
+    """ONDISK_MULTIPROC over a memory-mapped .npy slide: the iterators and predict_full_patched give exactly
+    what the resident mode gives (features, coords, patches, logits, class map)."""
+    from deephisto_amd.examples.predict_full_patched import predict_full_patched
+    from deephisto_amd.patch_samplers.full_samplers import FullImageDenseSampler, SamplerExecutionMode
+    host = synth.synth_slide(700, 1100, 9)
+    path = tmp_path / "slide.npy"
+    np.save(path, host)
+    kw = dict(layer=1, patch_size=128, batch_size=8, stride=96, device=dev)
+    res = FullImageDenseSampler(host, mode=SamplerExecutionMode.INMEMORY_SINGLEPROC, **kw)
+    disk = FullImageDenseSampler(path, mode=SamplerExecutionMode.ONDISK_MULTIPROC, **kw)
+    assert not disk.resident and res.resident and (disk.h, disk.w) == (700, 1100)
+    with pytest.raises(AttributeError):
+        disk.data_device
+    np.testing.assert_array_equal(disk.origins, res.origins)
+    n = 0
+    for (fa, ca, pa), (fb, cb, pb) in zip(res.generator_torch(), disk.generator_torch()):
+        assert torch.equal(fa, fb) and torch.equal(ca, cb) and pa == pb
+        n += 1
+    assert n == len(res)
+    for (xa, oa, _), (xb, ob, _) in zip(res.generator_device(), disk.generator_device()):
+        assert torch.equal(xa, xb) and np.array_equal(oa, ob)
+    pa, _ = next(iter(disk))
+    np.testing.assert_array_equal(pa[3].data, host[pa[3].pos_y:pa[3].pos_y + 128, pa[3].pos_x:pa[3].pos_x + 128])
+    oracle = oracle_net.seeded_model(5, 5, perturb_bn=True).eval()
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    model = get_model(5, "bf16")
+    model.load_state_dict(oracle.state_dict())
+    model.to(dev).eval()
+    cm_a, lg_a = predict_full_patched(res, model, 5, downscale=16, micro_batch=16, return_logits=True, streams=1)
+    cm_b, lg_b = predict_full_patched(disk, model, 5, downscale=16, micro_batch=16, return_logits=True, streams=1)
+    assert torch.equal(lg_a, lg_b) and torch.equal(cm_a, cm_b)
