@@ -713,11 +713,14 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
   return DH_OK;
 }
 
-template <typename T, int STRIDE, int NT, int WAVES, bool DS = false, int MT = 2>
+template <typename T, int STRIDE, int NT, int WAVES, bool DS = false, int MT = 2, bool WRES = false>
 int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   const int win_bytes = p.IMGS * p.HR * p.HP * CHUNK_BYTES;
-  const size_t buf = (size_t)(9 + (DS ? 1 : 0)) * SLAB_TAP + ((win_bytes + 1023) & ~1023);
-  const size_t lds = 2 * buf + (DS ? 2048 : 1024);  // 2-deep ring + [2][scale|shift(|ds scale|ds shift)]
+  const size_t wslab = (size_t)(9 + (DS ? 1 : 0)) * SLAB_TAP, win_alloc = (win_bytes + 1023) & ~1023;
+  const size_t nchunks = (size_t)L.cin * sizeof(T) / CHUNK_BYTES;
+  // 2-deep ring of [weight slab | window] (WRES: all weight slabs once + ring of windows) + [2][scale|shift(|ds scale|ds shift)]
+  const size_t lds = (WRES ? nchunks * wslab + 2 * win_alloc : 2 * (wslab + win_alloc)) + (DS ? 2048 : 1024);
+  DH_REQUIRE(!WRES || L.cout == 64, "conv3x3: resident weights need a single cout block");
   constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
   p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
   DH_REQUIRE(p.n_win_instr <= MAXJ * WAVES, "conv3x3: staging window too large for the DMA plan");
@@ -734,14 +737,14 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   p.lane_tab = tb.lane; p.tile_tab = tb.tile;
   static bool attr_set = false;
   if (!attr_set) {
-    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT>),
+    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT>),
+    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT>), dim3(grid), dim3(WAVES * 64), lds, st, p);
-  else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
@@ -806,6 +809,11 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     p.HR = p.TH + 2; p.HC = p.TW + 2;
     p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
     if ((rc = maybe_sample(variant == 0))) return rc;
+    // weights resident in LDS when the layer has one cout block and its slabs fit beside the window ring (bf16 64 -> 64)
+    const size_t wres_lds = (size_t)L.cin * sizeof(T) / CHUNK_BYTES * 9 * SLAB_TAP + 2 * (((size_t)p.IMGS * p.HR * p.HP * CHUNK_BYTES + 1023) & ~(size_t)1023) + 1024;
+    if (variant == 0 && sizeof(T) == 2 && L.cout == 64 && wres_lds <= 160 * 1024)
+      rc = launch_conv3x3_cfg<T, 1, 2, 8, false, 2, true>(p, L, st);
+    else
     rc = variant == 0 ? launch_conv3x3_cfg<T, 1, 2, 8>(p, L, st)
        : variant == 1 ? launch_conv3x3_cfg<T, 1, 1, 8>(p, L, st)
                       : launch_conv3x3_cfg<T, 1, 1, 8, false, 1>(p, L, st);
