@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--patch", type=int, default=256)
     ap.add_argument("--stride", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64, help="sampler batch size (grid padding unit)")
-    ap.add_argument("--micro-batch", type=int, default=256, help="tiles per kernel launch")
+    ap.add_argument("--micro-batch", type=int, default=1024, help="tiles per kernel launch")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams (micro-batches in flight)")
     ap.add_argument("--downscale", type=int, default=16)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
@@ -202,8 +202,10 @@ def main():
         flop_tile = FLOP_PER_TILE_256 * (args.patch / 256.0) ** 2
         traffic = None   # HBM bytes per launch of the dominant kernel: from the committed PMC passes (rocprofv3
         pmc = REPO / "profiles" / "r01_pmc_dominant_kernel.json"   # cannot run inside the timed process)
-        if pmc.exists() and args.micro_batch == 256 and args.dtype == "bf16" and args.patch == 256:
-            traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
+        if pmc.exists() and args.dtype == "bf16" and args.patch == 256:
+            doc = json.loads(pmc.read_text())
+            if doc.get("micro_batch") == args.micro_batch:
+                traffic = doc["traffic_bytes_per_launch"]
         out = {
             "metric": "256x256 patches/sec WSI inference (predict_full_patched)",
             "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -21,24 +21,29 @@ GFLOP = {"L1 s1 c64": 2 * 64 * 64 * 64 * 64 * 9, "L2 s1 c128": 2 * 32 * 32 * 128
 def main(path, micro_batch=256):
     f = glob.glob(path + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    agg = collections.defaultdict(list)
-    pos = None
+    # group the launches of one forward (stem ... avgpool+fc); short (last, partial) micro-batches are recognised by
+    # their stem time and left out of the per-layer averages
+    forwards, other = [], collections.defaultdict(list)
     for r in rows:
         n = r["Kernel_Name"]
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        full = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) >= 256   # persistent grid filled = full micro-batch
         if "stem_pool" in n:
-            pos = 0
-            lab = "stem+pool"
-        elif "conv3x3_kernel" in n and pos is not None and pos < len(SEQ):
-            lab = SEQ[pos]
-            pos += 1
+            forwards.append([("stem+pool", us)])
+        elif "conv3x3_kernel" in n and forwards and len(forwards[-1]) <= len(SEQ):
+            forwards[-1].append((SEQ[len(forwards[-1]) - 1], us))
         else:
             lab = next((v for k, v in (("avgpool", "avgpool+fc"), ("accumulate", "accumulate"), ("argmax", "argmax"),
                                        ("gather", "gather"), ("synth", "synth")) if k in n), None)
-            full = True
-        if lab and full:
-            agg[lab].append(us)
+            if lab:
+                other[lab].append(us)
+    stems = sorted(fw[0][1] for fw in forwards)
+    median = stems[len(stems) // 2] if stems else 0.0
+    agg = collections.defaultdict(list)
+    for fw in forwards:
+        if fw[0][1] >= 0.8 * median:
+            for lab, us in fw:
+                agg[lab].append(us)
+    agg.update(other)
     tot = sum(sum(v) for v in agg.values())
     print(f"{'kernel':12s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'share':>7s} {'TFLOP/s':>8s}   (full micro-batches of {micro_batch} only)")
     for k in ["stem+pool"] + sorted(set(SEQ), key=SEQ.index) + ["avgpool+fc", "accumulate", "argmax", "synth"]:
