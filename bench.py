@@ -221,7 +221,7 @@ def main():
                        "n_tiles": n_tiles, "n_classes": 5,
                        "parallelism": f"tile-range shard x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
             "model_tflops": value * flop_tile / 1e12,
-            "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<{args.dtype}, stride 1, NT=2, 8 waves> (layers 1-3, 10 of 20 convs)",
+            "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<{args.dtype}, stride 1, NT=2, 8 waves> (layers 1-3, 10 of 20 convs; two instantiations: layer 1 keeps its weights resident in LDS)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "launches_timed": int(k_n.value),
