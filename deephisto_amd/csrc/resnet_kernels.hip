@@ -720,7 +720,7 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   const size_t nchunks = (size_t)L.cin * sizeof(T) / CHUNK_BYTES;
   // 2-deep ring of [weight slab | window] (WRES: all weight slabs once + ring of windows) + [2][scale|shift(|ds scale|ds shift)]
   const size_t lds = (WRES ? nchunks * wslab + 2 * win_alloc : 2 * (wslab + win_alloc)) + (DS ? 2048 : 1024);
-  DH_REQUIRE(!WRES || L.cout == 64, "conv3x3: resident weights need a single cout block");
+
   constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
   p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
   DH_REQUIRE(p.n_win_instr <= MAXJ * WAVES, "conv3x3: staging window too large for the DMA plan");
@@ -730,6 +730,7 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   const int groups = ((p.B + p.IMGS - 1) / p.IMGS) * p.tiles_y * p.tiles_x;
   p.ntiles = groups * (L.cout / 64);
   const int grid = std::min(256, p.ntiles);  // persistent: one workgroup per CU
+  DH_REQUIRE(!WRES || grid % (L.cout / 64) == 0, "conv3x3: resident weights need a fixed cout block per workgroup");
   p.iters = (p.ntiles + grid - 1) / grid;
   Conv3Tables tb;
   int rc = conv3_tables<STRIDE, NT, WAVES, (int)sizeof(T), MT>(p, L.cout / 64, groups, &tb);
@@ -811,7 +812,7 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     if ((rc = maybe_sample(variant == 0))) return rc;
     // weights resident in LDS when the layer has one cout block and its slabs fit beside the window ring (bf16 64 -> 64)
     const size_t wres_lds = (size_t)L.cin * sizeof(T) / CHUNK_BYTES * 9 * SLAB_TAP + 2 * (((size_t)p.IMGS * p.HR * p.HP * CHUNK_BYTES + 1023) & ~(size_t)1023) + 1024;
-    if (variant == 0 && sizeof(T) == 2 && L.cout == 64 && wres_lds <= 160 * 1024)
+    if (variant == 0 && sizeof(T) == 2 && wres_lds <= 160 * 1024)
       rc = launch_conv3x3_cfg<T, 1, 2, 8, false, 2, true>(p, L, st);
     else
     rc = variant == 0 ? launch_conv3x3_cfg<T, 1, 2, 8>(p, L, st)
@@ -823,7 +824,10 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     p.HR = 2 * p.TH + 1; p.HC = 2 * p.TW + 1; p.HPH = p.TW + 1; p.HP = 2 * p.HPH;
     p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
     // 128-pixel tiles, 8 waves: wave pairs share pixels and split the 64 couts (two waves per SIMD)
-    rc = ds ? launch_conv3x3_cfg<T, 2, 1, 8, true, 1>(p, L, st) : launch_conv3x3_cfg<T, 2, 1, 8, false, 1>(p, L, st);
+    const size_t wres_lds = (size_t)L.cin * sizeof(T) / CHUNK_BYTES * (ds ? 10 : 9) * SLAB_TAP
+                          + 2 * (((size_t)p.IMGS * p.HR * p.HP * CHUNK_BYTES + 1023) & ~(size_t)1023) + 2048;
+    if (ds && sizeof(T) == 2 && wres_lds <= 160 * 1024) rc = launch_conv3x3_cfg<T, 2, 1, 8, true, 1, true>(p, L, st);
+    else rc = ds ? launch_conv3x3_cfg<T, 2, 1, 8, true, 1>(p, L, st) : launch_conv3x3_cfg<T, 2, 1, 8, false, 1>(p, L, st);
   }
   if (rc) return rc;
   if (sample) {
