@@ -696,12 +696,31 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
       row[2 * NT + 2 * j + 1] = (hy & 0xFF) | ((hx & 0xFF) << 8) | ((img & 0xFF) << 16) | ((live ? 1 : 0) << 24);
     }
   }
+  // Schedule [iters][grid]: which (pixel tile, cout block) a workgroup takes in which iteration.  Workgroups are
+  // dispatched round-robin over the 8 XCDs (workgroup w -> XCD w % 8), each with its own 4 MiB L2.  When the layer's
+  // weights fit an L2 several times over (`xcd_group`), the ncb cout blocks of a pixel tile go to ncb workgroups of
+  // ONE XCD in the same iteration, so the staged window is fetched into that L2 once and hit ncb - 1 times.
+  // Otherwise (512-channel layers) cout block = workgroup % ncb: every XCD keeps one slice of the weights in its L2.
+  // Either way a workgroup keeps its cout block for all iterations (resident-weight variants rely on it).
   const int tiles_per_img = p.tiles_y * p.tiles_x;
-  std::vector<int4> tile((size_t)p.ntiles);
-  for (int T_ = 0; T_ < p.ntiles; ++T_) {
-    const int pt = T_ / ncb, t = pt % tiles_per_img;
-    tile[T_] = make_int4(T_ % ncb, (pt / tiles_per_img) * p.IMGS, (t / p.tiles_x) * p.TH, (t % p.tiles_x) * p.TW);
-  }
+  const int grid = std::min(256, p.ntiles), n_pt = p.ntiles / ncb;
+  const bool xcd_group = ncb > 1 && grid == 256 && 32 % ncb == 0 && (int64_t)p.Cout * p.Cin * 9 * ESZ <= (1 << 21);
+  std::vector<int4> tile((size_t)p.iters * grid);
+  for (int it = 0; it < p.iters; ++it)
+    for (int w = 0; w < grid; ++w) {
+      int cb, pt;
+      if (xcd_group) {
+        const int xcd = w % 8, slot = w / 8;
+        cb = slot % ncb;
+        pt = it * (grid / ncb) + (slot / ncb) * 8 + xcd;
+      } else {
+        const int T_ = it * grid + w;
+        cb = T_ % ncb; pt = T_ / ncb;
+      }
+      const int valid = pt < n_pt ? 1 : 0, t = pt % tiles_per_img;
+      tile[(size_t)it * grid + w] = make_int4(cb | (valid << 16), (pt / tiles_per_img) * p.IMGS, (t / p.tiles_x) * p.TH,
+                                              (t % p.tiles_x) * p.TW);
+    }
   Conv3Tables tb;
   DH_HIP(hipMalloc((void**)&tb.lane, lane.size() * sizeof(int)));
   DH_HIP(hipMalloc((void**)&tb.tile, tile.size() * sizeof(int4)));
