@@ -697,14 +697,15 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
     }
   }
   // Schedule [iters][grid]: which (pixel tile, cout block) a workgroup takes in which iteration.  Workgroups are
-  // dispatched round-robin over the 8 XCDs (workgroup w -> XCD w % 8), each with its own 4 MiB L2.  When the layer's
-  // weights fit an L2 several times over (`xcd_group`), the ncb cout blocks of a pixel tile go to ncb workgroups of
-  // ONE XCD in the same iteration, so the staged window is fetched into that L2 once and hit ncb - 1 times.
-  // Otherwise (512-channel layers) cout block = workgroup % ncb: every XCD keeps one slice of the weights in its L2.
+  // dispatched round-robin over the 8 XCDs (workgroup w -> XCD w % 8), each with its own 4 MiB L2.  The ncb cout
+  // blocks of a pixel tile go to ncb workgroups of ONE XCD in the same iteration (`xcd_group`), so the staged window
+  // is fetched into that L2 once and hit ncb - 1 times; measured -8 % (layer 2) ... -16 % (stride-2 layers) against
+  // cout block = workgroup % ncb (one weight slice per XCD), also for the 512-channel layers whose 4.7 MB of weights
+  // no longer fit one L2 (they come from the Infinity Cache instead).
   // Either way a workgroup keeps its cout block for all iterations (resident-weight variants rely on it).
   const int tiles_per_img = p.tiles_y * p.tiles_x;
   const int grid = std::min(256, p.ntiles), n_pt = p.ntiles / ncb;
-  const bool xcd_group = ncb > 1 && grid == 256 && 32 % ncb == 0 && (int64_t)p.Cout * p.Cin * 9 * ESZ <= (1 << 21);
+  const bool xcd_group = ncb > 1 && grid == 256 && 32 % ncb == 0 && (int64_t)p.Cout * p.Cin * 9 * ESZ <= (1 << 23);
   std::vector<int4> tile((size_t)p.iters * grid);
   for (int it = 0; it < p.iters; ++it)
     for (int w = 0; w < grid; ++w) {
