@@ -910,9 +910,9 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
     sp.w = net->convs[0].w_dev; sp.scale = net->convs[0].scale_dev; sp.shift = net->convs[0].shift_dev; sp.out = bufA;
     sp.B = B; sp.P = P; sp.Hc = H1; sp.Wc = H1; sp.Hp = H2; sp.Wp = H2;
     sp.tiles_y = (H2 + SP_PR - 1) / SP_PR; sp.tiles_x = (H2 + SP_PC - 1) / SP_PC;
-    sp.ntiles = B * sp.tiles_y * sp.tiles_x;
-    const int grid = std::min(768, sp.ntiles);   // persistent: three 4-wave workgroups per CU
-    sp.iters = (sp.ntiles + grid - 1) / grid;
+    sp.nstrips = B * sp.tiles_x;                 // a strip = one image x 15 pooled columns, swept top to bottom
+    const int grid = std::min(768, sp.nstrips);  // persistent: three 4-wave workgroups per CU
+    sp.iters = ((sp.nstrips + grid - 1) / grid) * sp.tiles_y;
     static bool a = false;
     if (!a) {
       DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
