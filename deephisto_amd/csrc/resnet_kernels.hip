@@ -267,7 +267,6 @@ constexpr int STEM_TH = 8, STEM_TW = 32;
 constexpr int STEM_ROWS = 2 * STEM_TH + 5;   // 21 input rows
 constexpr int STEM_ROWE = 224;               // elements per staged row (>= 6*31 + 32)
 constexpr int STEM_REAL = 1 + 3 * (2 * STEM_TW + 5);  // 208 meaningful elements (slot 0 = dummy)
-constexpr int STEM_KW_BF16 = 32, STEM_KW_F32 = 22;    // k-slice width per tap row
 
 struct StemParams {
   const float* x_nchw; const uint8_t* slide; const int32_t* yx; int64_t row_bytes;
