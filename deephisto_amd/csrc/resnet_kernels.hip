@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, 
 // global average pool + fc: one workgroup per image; f32 arithmetic.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void avgpool_fc_kernel(const T* __restrict__ in, int HW, int C,
+__global__ __launch_bounds__(256) void avgpool_fc_kernel(const T* __restrict__ in, int HW, int C, int blocked,
                                                          const float* __restrict__ fc_w,
                                                          const float* __restrict__ fc_b, int n_cls,
                                                          float* __restrict__ logits) {
@@ -452,7 +452,10 @@ __global__ __launch_bounds__(256) void avgpool_fc_kernel(const T* __restrict__ i
 #pragma unroll
   for (int e = 0; e < EPV; ++e) s[e] = 0.f;
   for (int q = grp; q < HW; q += groups) {
-    const uint4 v = *reinterpret_cast<const uint4*>(in + ((int64_t)b * HW + q) * C + cl * EPV);
+    // NHWC, or channel-blocked [image][C/32][HW][32] (a lane's 16 bytes never straddle a 32-channel chunk)
+    const int64_t off = blocked ? (int64_t)b * HW * C + (int64_t)((cl * EPV) >> 5) * HW * 32 + q * 32 + ((cl * EPV) & 31)
+                                : ((int64_t)b * HW + q) * C + cl * EPV;
+    const uint4 v = *reinterpret_cast<const uint4*>(in + off);
     const uint32_t u[4] = {v.x, v.y, v.z, v.w};
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -653,7 +656,7 @@ template <int STRIDE, int NT, int WAVES, int ESZ, int MT>
 int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out) {
   constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
   const std::vector<int> key = {STRIDE, NT, WAVES, MT, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi, p.Cin,
-                                p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr};
+                                p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes};
   auto it = g_conv3_tables.find(key);
   if (it != g_conv3_tables.end()) { *out = it->second; return DH_OK; }
   const int threads = WAVES * 64, stride = 2 * NT + 2 * MAXJ;
@@ -691,7 +694,7 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
       if (STRIDE == 2) hx = 2 * (c % p.HPH) + c / p.HPH;
       const bool live = i < p.n_win_instr && img < p.IMGS && hx < p.HC;
       const int g = (l & 3) ^ ((px >> 2) & 3);
-      row[2 * NT + 2 * j] = ((img * p.Hi + hy - 1) * p.Wi + hx - 1) * p.Cin * ESZ + g * 16;
+      row[2 * NT + 2 * j] = img * p.Hi * p.Wi * p.Cin * ESZ + ((hy - 1) * p.Wi + hx - 1) * p.in_px_bytes + g * 16;
       row[2 * NT + 2 * j + 1] = (hy & 0xFF) | ((hx & 0xFF) << 8) | ((img & 0xFF) << 16) | ((live ? 1 : 0) << 24);
     }
   }
@@ -771,8 +774,17 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
 
 template <typename T, int STRIDE>
 int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* out, int B, int Hi, int Wi,
-                   bool relu, hipStream_t st, int Ho, int Wo, const ConvLayer* ds = nullptr, void* ds_out = nullptr) {
+                   bool relu, hipStream_t st, int Ho, int Wo, const ConvLayer* ds = nullptr, void* ds_out = nullptr,
+                   bool blocked = false) {
   Conv3Params p;
+  DH_REQUIRE(!blocked || sizeof(T) == 2, "conv3x3: the channel-blocked layout is the bf16 inference layout");
+  if (blocked) {   // [image][C/32][H][W][32]
+    p.in_px_bytes = CHUNK_BYTES; p.in_chunk_bytes = Hi * Wi * CHUNK_BYTES;
+    p.out_px = 32; p.out_mt = Ho * Wo * 32; p.out_cb = 2 * p.out_mt;
+  } else {         // NHWC
+    p.in_px_bytes = L.cin * (int)sizeof(T); p.in_chunk_bytes = CHUNK_BYTES;
+    p.out_px = L.cout; p.out_mt = 32; p.out_cb = 64;
+  }
   p.ds_w = ds ? ds->w_dev : nullptr; p.ds_scale = ds ? ds->scale_dev : nullptr;
   p.ds_shift = ds ? ds->shift_dev : nullptr; p.ds_out = ds_out;
   p.in = in; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = out;
@@ -859,14 +871,15 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
 
 template <typename T>
 int run_conv(const ConvLayer& L, const void* in, const void* res, void* out, int B, int Hi, int Wi,
-             bool relu, hipStream_t st, int* Ho_out, int* Wo_out) {
+             bool relu, hipStream_t st, int* Ho_out, int* Wo_out, bool blocked = false) {
   const int pad = L.ks / 2;
   const int Ho = (Hi + 2 * pad - L.ks) / L.stride + 1, Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
   *Ho_out = Ho; *Wo_out = Wo;
   DH_REQUIRE((int64_t)B * Hi * Wi * L.cin * (int64_t)sizeof(T) < ((int64_t)1 << 32),
              "conv %s: input larger than 4 GiB, reduce the batch", L.name.c_str());
-  if (L.ks == 3 && L.stride == 1) return launch_conv3x3<T, 1>(L, in, res, out, B, Hi, Wi, relu, st, Ho, Wo);
-  if (L.ks == 3 && L.stride == 2) return launch_conv3x3<T, 2>(L, in, res, out, B, Hi, Wi, relu, st, Ho, Wo);
+  if (L.ks == 3 && L.stride == 1) return launch_conv3x3<T, 1>(L, in, res, out, B, Hi, Wi, relu, st, Ho, Wo, nullptr, nullptr, blocked);
+  if (L.ks == 3 && L.stride == 2) return launch_conv3x3<T, 2>(L, in, res, out, B, Hi, Wi, relu, st, Ho, Wo, nullptr, nullptr, blocked);
+  DH_REQUIRE(!blocked, "conv %s: only the 3x3 kernels read the channel-blocked layout", L.name.c_str());
   ConvParams p;
   p.in = in; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = out;
   p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = L.cin; p.Cout = L.cout; p.Ho = Ho; p.Wo = Wo;
@@ -962,7 +975,9 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
     DH_LAUNCH_CHECK();
   }
   }
-  // residual stages: X lives in bufA; T in bufB; downsample in bufC
+  // residual stages: X lives in bufA; T in bufB; downsample in bufC.  bf16 activations are channel-blocked
+  // ([image][C/32][H][W][32], written that way by the fused stem), f32 activations NHWC.
+  constexpr bool BLK = sizeof(T) == 2;
   int H = H2, W = H2;
   size_t ci = 1;
   for (int s = 0; s < 4; ++s) {
@@ -976,21 +991,21 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
       if (has_ds) {
         // conv1 (3x3/2 + BN + ReLU) and the 1x1/2 downsample (+ BN) of the block in ONE launch
         Ho = (H + 2 - 3) / 2 + 1; Wo = (W + 2 - 3) / 2 + 1;
-        rc = launch_conv3x3<T, 2>(c1, bufA, nullptr, bufB, B, H, W, true, st, Ho, Wo, &net->convs[ci + 2], bufC);
+        rc = launch_conv3x3<T, 2>(c1, bufA, nullptr, bufB, B, H, W, true, st, Ho, Wo, &net->convs[ci + 2], bufC, BLK);
         if (rc) return rc;
         resid = bufC;
       } else {
-        rc = run_conv<T>(c1, bufA, nullptr, bufB, B, H, W, true, st, &Ho, &Wo);
+        rc = run_conv<T>(c1, bufA, nullptr, bufB, B, H, W, true, st, &Ho, &Wo, BLK);
         if (rc) return rc;
       }
-      rc = run_conv<T>(c2, bufB, resid, bufA, B, Ho, Wo, true, st, &h2, &w2);
+      rc = run_conv<T>(c2, bufB, resid, bufA, B, Ho, Wo, true, st, &h2, &w2, BLK);
       if (rc) return rc;
       H = Ho; W = Wo;
       ci += has_ds ? 3 : 2;
     }
   }
   hipLaunchKernelGGL((avgpool_fc_kernel<T>), dim3(B), dim3(256), 0, st, static_cast<const T*>(bufA), H * W,
-                     512, net->fc_w_dev, net->fc_b_dev, net->n_classes, logits);
+                     512, BLK ? 1 : 0, net->fc_w_dev, net->fc_b_dev, net->n_classes, logits);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
