@@ -444,6 +444,26 @@ class AnnoRegionRndSampler:
                 yield self._assemble(recs[k:k + batch_size], DH_LAYOUT_NCHW, dtype, fh, fv)
 
 
+    def torch_iterable_dataset(self):
+        """Endless `IterableDataset` of single (features f32[P,P,3] = uint8/255, label int64, coords f32[2]) samples
+        for use with a DataLoader (region_samplers.py:740-786).  Samples are cut on the GPU
+        `patches_from_one_region` at a time; coords are (pos_y, pos_x) -- the reference's inner generator
+        writes pos_y twice (:770-772), which looks unintended and is not reproduced."""
+        from torch.utils.data import IterableDataset
+
+        sampler = self
+
+        class _Dataset(IterableDataset):
+            def __iter__(self):
+                while True:
+                    recs = sampler._records(sampler.patches_from_one_region)
+                    f, lab, c = sampler._assemble(recs, DH_LAYOUT_NHWC, torch.float32)
+                    for i in range(len(recs)):
+                        yield f[i], lab[i], c[i]
+
+        return _Dataset()
+
+
 class AnnoRegionDenseSampler:
     """Every grid patch of every annotated region, class by class (region_samplers.py:799-871)."""
 

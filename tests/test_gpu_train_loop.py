@@ -139,6 +139,14 @@ def test_anno_region_sampler_device_batches(dev):
         if fh: want = torch.flip(want, dims=[2])
         if fv: want = torch.flip(want, dims=[1])
         assert torch.equal(x[i].cpu(), want)
+    # endless single-sample dataset
+    np.random.seed(23)
+    it = iter(smp.torch_iterable_dataset())
+    f0, l0, c0 = next(it)
+    assert tuple(f0.shape) == (96, 96, 3) and l0.dtype == torch.int64 and tuple(c0.shape) == (2,)
+    y0, x0 = int(c0[0]), int(c0[1])
+    assert any(torch.equal(f0.cpu(), torch.from_numpy(im[y0:y0 + 96, x0:x0 + 96].astype(np.float32) / 255))
+               for im in imgs if y0 + 96 <= im.shape[0] and x0 + 96 <= im.shape[1])
     # and the training step consumes it
     from deephisto_amd.models.patch_cls_simple.model import get_model
     torch.manual_seed(0)
