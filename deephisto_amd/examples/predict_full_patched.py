@@ -187,6 +187,8 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     lo, hi = shard_range(n_unique, world, rank)
+    if hi - lo > mb:   # equal launches instead of full ones plus a short tail (4 802 tiles per rank at 8 GPUs: 5 x 961)
+        mb = -(-(hi - lo) // -(-(hi - lo) // mb))
     o_dev = torch.from_numpy(origins[lo:hi]).to(dev)
     per_rank = -(-n_unique // world)
     local = torch.zeros((per_rank, n_classes), dtype=torch.float32, device=dev)
