@@ -1,33 +1,31 @@
-"""Mirror of models/patch_cls_simple/utils.py:1-17 (config loader, device picker)."""
+"""Config loader, device picker and dataset listing of the training entry point.
+
+Behaviour of models/patch_cls_simple/utils.py:1-17 (YAML -> dict; device preference mps, then
+cuda, then cpu) and of the reference's top-level utils.py:4-14 (image / annotation pairs)."""
+from __future__ import annotations
+
+from pathlib import Path
 
 
-def load_config(config_path):
+def load_config(config_path) -> dict:
+    """Parse the YAML training configuration (safe loader) into a plain dict."""
     import yaml
 
-    with open(config_path, "r") as file:
-        return yaml.safe_load(file)
+    return yaml.safe_load(Path(config_path).read_text())
 
 
 def get_device():
-    """Same preference order as the reference (utils.py:8-17): mps if built, else
-    cuda, else cpu.  On PyTorch-ROCm `mps.is_built()` is False and an MI355X shows
-    up as "cuda"."""
+    """First available of ("mps" when torch was built with it, "cuda", "cpu") -- the reference's
+    preference order.  On PyTorch-ROCm an MI355X is reported as "cuda"."""
     import torch
 
-    if torch.backends.mps.is_built():
-        device = torch.device("mps")
-    elif torch.cuda.is_available():
-        device = torch.device("cuda")
-    else:
-        device = torch.device("cpu")
-    return device
+    candidates = (("mps", torch.backends.mps.is_built), ("cuda", torch.cuda.is_available), ("cpu", lambda: True))
+    return torch.device(next(name for name, available in candidates if available()))
 
 
-def get_img_ano_paths(ds_folder, sample: str = "train"):
-    """(image, annotation) path pairs of a dataset folder: `images/<sample>/*.psi` with
-    `annotations/<sample>/<stem>.json` (the reference's top-level utils.py:4-14)."""
-    from pathlib import Path
-
-    ds_folder = Path(ds_folder)
-    img_paths = [p for p in (ds_folder / "images" / sample).iterdir() if p.is_file() and p.suffix == ".psi"]
-    return [(p, ds_folder / "annotations" / sample / f"{p.stem}.json") for p in img_paths]
+def get_img_ano_paths(ds_folder, sample: str = "train") -> list[tuple[Path, Path]]:
+    """(image, annotation) pairs of a dataset folder: every `images/<sample>/*.psi` with its
+    `annotations/<sample>/<stem>.json`."""
+    root = Path(ds_folder)
+    images = sorted(p for p in (root / "images" / sample).iterdir() if p.is_file() and p.suffix == ".psi")
+    return [(img, root / "annotations" / sample / (img.stem + ".json")) for img in images]
