@@ -143,3 +143,23 @@ def test_model_errors(dev):
         m(torch.zeros(1, 3, 64, 64))
     with pytest.raises(ValueError):
         m(torch.zeros(1, 4, 64, 64, device=dev))
+
+
+@pytest.mark.parametrize("dtype,P,n", [("bf16", 256, 70), ("bf16", 224, 300), ("f32", 128, 130)])
+def test_large_launch_matches_small_launches(dev, dtype, P, n):
+    """Launches with >= 256 conv tiles use the XCD-grouped persistent schedule (several iterations per workgroup,
+    the last one partial, resident weights, 512-pixel tiles); launches of a few tiles use one tile per workgroup and
+    smaller tile variants.  The per-tile arithmetic is the same, so the logits must be IDENTICAL -- and the small
+    launches are the ones checked against the CPU oracle above."""
+    from deephisto_amd import tiles
+    oracle = oracle_net.seeded_model(31, 5, perturb_bn=True).eval()
+    model = _hip_model(oracle, dev, dtype)
+    side = 4096
+    slide = tiles.synth_slide(side, side, 3, dev)
+    rng = np.random.default_rng(n)
+    o = np.stack([rng.integers(0, side - P, n), rng.integers(0, side - P, n)], 1).astype(np.int32)
+    o_dev = torch.from_numpy(o).to(dev)
+    big = model.forward_tiles(slide, o_dev, P)
+    small = torch.cat([model.forward_tiles(slide, o_dev[i:i + 7].contiguous(), P) for i in range(0, n, 7)])
+    assert torch.equal(big, small)
+    assert bool(torch.isfinite(big).all()) and float(big.abs().max()) > 0

@@ -137,3 +137,30 @@ def test_ce_loss_kernel(dev):
     want.backward()
     assert abs(float(loss) - float(want)) <= 1e-5
     assert float((dl.cpu() - lr.grad).abs().max()) <= 1e-6
+
+
+def test_bench_shape_step_matches_oracle(dev):
+    """Batch 64 x 224^2 (the bench's training shape): the convolutions run with >= 256 tiles per launch, i.e. the
+    persistent XCD-grouped schedule, the 9-tap wgrad with 14-row slabs, the 8x64 / 16x16 / 8x8x2 tile variants --
+    none of which the small parity cases above reach.  Loss and per-tensor relative L2 of the gradients against the
+    float32 CPU oracle (ReLU-mask switches allowed for, see test_forward_backward_matches_oracle)."""
+    ref, m = _pair(dev, 5)
+    g = torch.Generator().manual_seed(64224)
+    x = torch.rand(64, 3, 224, 224, generator=g)
+    y = torch.randint(0, 5, (64,), generator=g)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    out_ref = ref(x)
+    loss_ref = F.cross_entropy(out_ref, y)
+    loss_ref.backward()
+    out = m(x.to(dev))
+    loss = F.cross_entropy(out, y.to(dev))
+    loss.backward()
+    assert float((out.detach().cpu() - out_ref.detach()).abs().max()) <= 1e-4
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4
+    ref_g = {k: p.grad for k, p in ref.named_parameters()}
+    bad = {}
+    for k, p in m.named_parameters():
+        e = float((p.grad.cpu() - ref_g[k]).norm()) / (float(ref_g[k].norm()) + 1e-30)
+        if e > 2e-2:
+            bad[k] = e
+    assert not bad, bad
