@@ -1,0 +1,3 @@
+"""Reference path examples/predict_full_patched.py."""
+from deephisto_amd.examples.predict_full_patched import (ImagePredictorPatched, batch_predictor, load_model,  # noqa: F401
+                                                         perform_and_save_visualizations, predict_full_patched)

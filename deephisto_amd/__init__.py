@@ -6,3 +6,5 @@ mirrors the reference's interface; all computation runs in hand-written HIP
 kernels for gfx950 behind the C ABI of include/deephisto_hip.h.
 """
 __version__ = "0.1.0"
+
+from .aliases import install_aliases, uninstall_aliases  # noqa: E402,F401  (imports nothing heavy: modules load on call)

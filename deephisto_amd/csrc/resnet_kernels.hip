@@ -4,30 +4,31 @@
 // models/patch_cls_simple/model.py:5-11 (torchvision resnet18 + fc[n_cls,512]) as
 // called from examples/predict_full_patched.py:77 (eval mode).
 //
-// Design (see DESIGN.md section "a6"):
-//  * activations live in HBM as NHWC ("pixel-major") so the reduction index of
-//    every convolution, (tap, cin), is contiguous in cin: a 64-byte channel chunk
-//    of one pixel is one LDS row, and a lane's MFMA B-fragment is one 16-byte read;
+// Design:
+//  * activations live in HBM pixel-major: NHWC for float32, channel-blocked [image][C/32][H][W][32] for bf16
+//    inference, so the reduction index of every convolution, (tap, cin), is contiguous in cin: a 64-byte channel
+//    chunk of one pixel is one LDS row, and a lane's MFMA B-fragment is one 16-byte read;
 //  * each conv is an implicit GEMM  D[cout][pixel] = sum_k W[cout][k] * X[k][pixel]
-//    on v_mfma_f32_32x32x16_bf16 (bf16 mode) or v_mfma_f32_32x32x2_f32 (f32 mode,
-//    exact f32 products, used for the 1e-4 parity runs).  cout is the MFMA row
-//    index so every lane ends up with 4 consecutive couts of one pixel -> 8/16-byte
-//    NHWC stores with BN scale/shift, residual add and ReLU fused in the epilogue;
-//  * a workgroup (4 waves) owns 64 couts x 256 pixels (a 16x16 patch of one image,
-//    or 8x8 patches of 4 images).  For 3x3/stride-1 convs (85 % of the FLOPs) the
-//    input patch plus its 1-pixel halo is staged in LDS ONCE per 64-byte channel
-//    chunk and all 9 taps read shifted windows of it (LDS-staged im2col);
-//    stride-2 and 1x1 convs stage one tap at a time;
-//  * weights are pre-packed on the host in MFMA fragment order, so staging them is
-//    a linear 16-byte copy and reading them is conflict-free `base + lane*16`;
-//  * LDS per workgroup <= 68 KiB and <= 128 VGPRs -> two workgroups per CU, one
-//    staging while the other issues MFMAs.
+//    on v_mfma_f32_32x32x16_bf16 (bf16 mode) or v_mfma_f32_32x32x2_f32 (f32 mode, exact f32 products, used for
+//    the 1e-4 parity runs).  cout is the MFMA row index so every lane ends up with 4 consecutive couts of one
+//    pixel -> 8/16-byte stores with BN scale/shift, residual add and ReLU fused in the epilogue;
+//  * 3x3 convs (stride 1 and 2; the 1x1 stride-2 downsample rides on the stride-2 kernel): conv3x3.inc --
+//    persistent 8-wave workgroups, one per CU, 64 couts x 128..512 pixels per tile, LDS-DMA ring of
+//    [weight slab | input window] stages, all 9 taps read shifted views of the staged window;
+//  * bf16 stem: stem_pool.inc (conv 7x7/2 + BN + ReLU + maxpool fused, persistent); the generic conv_kernel
+//    below serves the f32 1x1 convs of training and the debug hook;
+//  * weights are pre-packed on the host in MFMA fragment order, so staging them is a linear copy and reading them
+//    is conflict-free `base + lane*16`;
+//  * host-side caches (lookup tables, zero page, function attributes) are keyed by HIP device and guarded by one
+//    mutex: one process may drive several devices / call from several threads (one handle per thread).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -627,6 +628,21 @@ struct Profiler {
   double flops = 0.0;
 } g_prof;
 
+// ---- per-device host state ---------------------------------------------------------------------------------
+std::mutex g_host_mu;   // guards every cache below (ctypes releases the GIL: two threads may be in here)
+inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+
+// hipFuncSetAttribute is per device: remember which (kernel, device) pairs are done
+int ensure_dyn_lds(const void* fn, int bytes) {
+  static std::set<std::pair<const void*, int>> done;
+  const std::pair<const void*, int> key(fn, current_device());
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  if (done.count(key)) return DH_OK;
+  DH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert(key);
+  return DH_OK;
+}
+
 template <typename T, int KS, int STRIDE, bool HALO>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   const int npx_lds = HALO ? p.IMGS * (p.TH + 2) * (p.TW + 2) : 256;
@@ -634,31 +650,47 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
   const int blocks_per_img = p.tiles_y * p.tiles_x;
   const int groups = ((p.B + p.IMGS - 1) / p.IMGS) * blocks_per_img;
   const int grid = groups * (p.Cout / 64);
-  static bool attr_set = false;
-  if (!attr_set) {
-    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, HALO>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_set = true;
-  }
+  if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv_kernel<T, KS, STRIDE, HALO>), 96 * 1024)) return rc;
   hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, HALO>), dim3(grid), dim3(256), lds, st, p);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
 
-void* g_zero_page = nullptr;  // 1 KiB of zeros: DMA source of padding pixels
+std::map<int, void*> g_zero_page;  // per device: 1 KiB of zeros, the DMA source of padding pixels
+int zero_page(const void** out) {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  auto it = g_zero_page.find(dev);
+  if (it == g_zero_page.end()) {
+    void* z = nullptr;
+    DH_HIP(hipMalloc(&z, 1024));
+    DH_HIP(hipMemset(z, 0, 1024));
+    it = g_zero_page.emplace(dev, z).first;
+  }
+  *out = it->second;
+  return DH_OK;
+}
 
-// Host-built lookup tables of the conv3x3 kernel, cached per layer shape for the life of the
-// process (a handful of shapes; a few KiB each): per-thread geometry and per-tile decode.
+// Host-built lookup tables of the conv3x3 kernel, cached per (device, layer shape): per-thread geometry and per-tile
+// decode, a few KiB each.  The key holds the batch only through the tile count; the cache is bounded (a caller that
+// sweeps batch sizes would otherwise grow it without end): past CONV3_TABLE_CAP entries of a device it is emptied
+// (hipFree waits for kernels that still read a table).
 struct Conv3Tables { int* lane = nullptr; int4* tile = nullptr; };
 std::map<std::vector<int>, Conv3Tables> g_conv3_tables;
+constexpr size_t CONV3_TABLE_CAP = 256;
 
 template <int STRIDE, int NT, int WAVES, int ESZ, int MT>
 int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out) {
   constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
-  const std::vector<int> key = {STRIDE, NT, WAVES, MT, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi, p.Cin,
-                                p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes};
+  const std::vector<int> key = {current_device(), STRIDE, NT, WAVES, MT, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi,
+                                p.Cin, p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes};
+  std::lock_guard<std::mutex> lk(g_host_mu);
   auto it = g_conv3_tables.find(key);
   if (it != g_conv3_tables.end()) { *out = it->second; return DH_OK; }
+  if (g_conv3_tables.size() >= CONV3_TABLE_CAP) {
+    for (auto& kv : g_conv3_tables) { (void)hipFree(kv.second.lane); (void)hipFree(kv.second.tile); }
+    g_conv3_tables.clear();
+  }
   const int threads = WAVES * 64, stride = 2 * NT + 2 * MAXJ;
   std::vector<int> lane((size_t)threads * stride);
   for (int tid = 0; tid < threads; ++tid) {
@@ -758,14 +790,8 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   int rc = conv3_tables<STRIDE, NT, WAVES, (int)sizeof(T), MT>(p, L.cout / 64, groups, &tb);
   if (rc) return rc;
   p.lane_tab = tb.lane; p.tile_tab = tb.tile;
-  static bool attr_set = false;
-  if (!attr_set) {
-    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES>), 160 * 1024)) ||
+      (rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>), 160 * 1024))) return rc;
   if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
   else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
   DH_LAUNCH_CHECK();
@@ -790,11 +816,7 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
   p.in = in; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = out;
   p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = L.cin; p.Cout = L.cout; p.Ho = Ho; p.Wo = Wo;
   p.relu = relu ? 1 : 0;
-  if (!g_zero_page) {
-    DH_HIP(hipMalloc(&g_zero_page, 1024));
-    DH_HIP(hipMemset(g_zero_page, 0, 1024));
-  }
-  p.zero_page = g_zero_page;
+  if (int zrc = zero_page(&p.zero_page)) return zrc;
   p.stamps = nullptr;
   if (g_stamps_on) {
     if (!g_stamps_dev) {
@@ -925,13 +947,10 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
     sp.nstrips = B * sp.tiles_x;                 // a strip = one image x 15 pooled columns, swept top to bottom
     const int grid = std::min(768, sp.nstrips);  // persistent: three 4-wave workgroups per CU
     sp.iters = ((sp.nstrips + grid - 1) / grid) * sp.tiles_y;
-    static bool a = false;
-    if (!a) {
-      DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
-      DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
-      DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_pool_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
-      a = true;
-    }
+    int arc;
+    if ((arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_pool_kernel<true, false>), SP_LDS)) ||
+        (arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_pool_kernel<true, true>), SP_LDS)) ||
+        (arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_pool_kernel<false, false>), SP_LDS))) return arc;
     sp.stamps = nullptr;
     if (g_stamps_on && slide) {
       if (!g_stamps_dev) {
@@ -956,12 +975,10 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
     const size_t lds = wb + (size_t)STEM_ROWS * STEM_ROWE * esz;
     const int grid = B * sp.tiles_y * sp.tiles_x;
     if (slide) {
-      static bool a = false;
-      if (!a) { DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); a = true; }
+      if (int arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_kernel<T, true>), 96 * 1024)) return arc;
       hipLaunchKernelGGL((stem_kernel<T, true>), dim3(grid), dim3(256), lds, st, sp);
     } else {
-      static bool a = false;
-      if (!a) { DH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); a = true; }
+      if (int arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_kernel<T, false>), 96 * 1024)) return arc;
       hipLaunchKernelGGL((stem_kernel<T, false>), dim3(grid), dim3(256), lds, st, sp);
     }
     DH_LAUNCH_CHECK();

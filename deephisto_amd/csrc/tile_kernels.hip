@@ -286,7 +286,7 @@ extern "C" int dh_tile_gather(const uint8_t* slide, int64_t h, int64_t w, const 
 // Gather with the batch-level flips of the training pipeline (train.py:71-81 applies
 // RandomHorizontalFlip / RandomVerticalFlip to the whole [B,C,H,W] batch: one coin per batch).
 template <bool BF16, bool NCHW>
-__global__ __launch_bounds__(256) void gather_aug_kernel(const uint8_t* __restrict__ slide, int64_t row_bytes,
+__global__ __launch_bounds__(256) void gather_aug_kernel(const uint8_t* __restrict__ slide, int64_t row_bytes, int h, int w,
                                                          const int32_t* __restrict__ yx, int P, int flip_h, int flip_v,
                                                          void* __restrict__ outv) {
   const int t = blockIdx.y;
@@ -298,7 +298,11 @@ __global__ __launch_bounds__(256) void gather_aug_kernel(const uint8_t* __restri
     if (NCHW) { c = (int)(i / ((int64_t)P * P)); const int rem = (int)(i - (int64_t)c * P * P); r = rem / P; px = rem - r * P; }
     else { r = (int)(i / (3 * P)); const int rem = (int)(i - (int64_t)r * 3 * P); px = rem / 3; c = rem - 3 * px; }
     const int sr = flip_v ? P - 1 - r : r, sx = flip_h ? P - 1 - px : px;
-    const float f = div255(slide[(int64_t)(y0 + sr) * row_bytes + (int64_t)(x0 + sx) * 3 + c]);
+    // region samplers keep the reference's origin bounds, which let a patch hang over the image border
+    // (region_samplers.py:112-118): pixels outside the slide read as 0, never as memory outside the allocation
+    const int yy = y0 + sr, xx = x0 + sx;
+    const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
+    const float f = in ? div255(slide[(int64_t)yy * row_bytes + (int64_t)xx * 3 + c]) : 0.f;
     const int64_t o = (int64_t)t * per_tile + i;
     if constexpr (BF16) static_cast<uint16_t*>(outv)[o] = (uint16_t)f32_to_bf16_bits(f);
     else static_cast<float*>(outv)[o] = f;
@@ -309,7 +313,7 @@ extern "C" int dh_tile_gather_aug(const uint8_t* slide, int64_t h, int64_t w, co
                                   int32_t layout, int32_t dtype, int32_t flip_h, int32_t flip_v, void* out, void* stream) {
   DH_REQUIRE(n >= 0 && n <= 65535, "tile gather aug: n=%lld out of range", (long long)n);
   if (n == 0) return DH_OK;
-  DH_REQUIRE(slide && yx_dev && out && P > 0 && h >= P && w >= P, "tile gather aug: bad arguments");
+  DH_REQUIRE(slide && yx_dev && out && P > 0 && h >= P && w >= P && h <= INT32_MAX && w <= INT32_MAX, "tile gather aug: bad arguments");
   DH_REQUIRE((layout == DH_LAYOUT_NHWC || layout == DH_LAYOUT_NCHW) && (dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16),
              "tile gather aug: bad layout/dtype");
   hipStream_t st = dh::as_stream(stream);
@@ -317,11 +321,11 @@ extern "C" int dh_tile_gather_aug(const uint8_t* slide, int64_t h, int64_t w, co
   dim3 grid((unsigned)std::min<int64_t>((per_tile + 255) / 256, 1024), (unsigned)n), block(256);
   const int64_t rb = w * 3;
   if (layout == DH_LAYOUT_NCHW) {
-    if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL((gather_aug_kernel<false, true>), grid, block, 0, st, slide, rb, yx_dev, P, flip_h, flip_v, out);
-    else hipLaunchKernelGGL((gather_aug_kernel<true, true>), grid, block, 0, st, slide, rb, yx_dev, P, flip_h, flip_v, out);
+    if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL((gather_aug_kernel<false, true>), grid, block, 0, st, slide, rb, (int)h, (int)w, yx_dev, P, flip_h, flip_v, out);
+    else hipLaunchKernelGGL((gather_aug_kernel<true, true>), grid, block, 0, st, slide, rb, (int)h, (int)w, yx_dev, P, flip_h, flip_v, out);
   } else {
-    if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL((gather_aug_kernel<false, false>), grid, block, 0, st, slide, rb, yx_dev, P, flip_h, flip_v, out);
-    else hipLaunchKernelGGL((gather_aug_kernel<true, false>), grid, block, 0, st, slide, rb, yx_dev, P, flip_h, flip_v, out);
+    if (dtype == DH_DTYPE_F32) hipLaunchKernelGGL((gather_aug_kernel<false, false>), grid, block, 0, st, slide, rb, (int)h, (int)w, yx_dev, P, flip_h, flip_v, out);
+    else hipLaunchKernelGGL((gather_aug_kernel<true, false>), grid, block, 0, st, slide, rb, (int)h, (int)w, yx_dev, P, flip_h, flip_v, out);
   }
   DH_LAUNCH_CHECK();
   return DH_OK;
@@ -329,14 +333,16 @@ extern "C" int dh_tile_gather_aug(const uint8_t* slide, int64_t h, int64_t w, co
 
 // NHWC float32 WITHOUT the /255 (FullImageRndSampler.generator_torch, full_samplers.py:286, yields the
 // raw 0..255 values as floats -- unlike the dense sampler).
-__global__ __launch_bounds__(256) void gather_raw_nhwc_kernel(const uint8_t* __restrict__ slide, int64_t row_bytes,
+__global__ __launch_bounds__(256) void gather_raw_nhwc_kernel(const uint8_t* __restrict__ slide, int64_t row_bytes, int h, int w,
                                                               const int32_t* __restrict__ yx, int P, float* __restrict__ out) {
   const int t = blockIdx.y;
   const int y0 = yx[2 * t], x0 = yx[2 * t + 1];
   const int64_t per_tile = (int64_t)P * P * 3;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_tile; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / (3 * P)), rem = (int)(i - (int64_t)r * 3 * P);
-    out[(int64_t)t * per_tile + i] = (float)slide[(int64_t)(y0 + r) * row_bytes + (int64_t)x0 * 3 + rem];
+    const int yy = y0 + r, xx = x0 + rem / 3;
+    const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;   // outside the slide: 0 (see gather_aug_kernel)
+    out[(int64_t)t * per_tile + i] = in ? (float)slide[(int64_t)yy * row_bytes + (int64_t)x0 * 3 + rem] : 0.f;
   }
 }
 
@@ -344,10 +350,10 @@ extern "C" int dh_tile_gather_raw(const uint8_t* slide, int64_t h, int64_t w, co
                                   float* out, void* stream) {
   DH_REQUIRE(n >= 0 && n <= 65535, "tile gather raw: n=%lld out of range", (long long)n);
   if (n == 0) return DH_OK;
-  DH_REQUIRE(slide && yx_dev && out && P > 0 && h >= P && w >= P, "tile gather raw: bad arguments");
+  DH_REQUIRE(slide && yx_dev && out && P > 0 && h >= P && w >= P && h <= INT32_MAX && w <= INT32_MAX, "tile gather raw: bad arguments");
   const int64_t per_tile = (int64_t)P * P * 3;
   dim3 grid((unsigned)std::min<int64_t>((per_tile + 255) / 256, 1024), (unsigned)n), block(256);
-  hipLaunchKernelGGL(gather_raw_nhwc_kernel, grid, block, 0, dh::as_stream(stream), slide, w * 3, yx_dev, P, out);
+  hipLaunchKernelGGL(gather_raw_nhwc_kernel, grid, block, 0, dh::as_stream(stream), slide, w * 3, (int)h, (int)w, yx_dev, P, out);
   DH_LAUNCH_CHECK();
   return DH_OK;
 }

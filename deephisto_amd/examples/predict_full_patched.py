@@ -221,7 +221,7 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
 def _forward_streamed(sampler, handle, origins: np.ndarray, local: torch.Tensor, n_classes: int, micro_batch: int):
     """Logits of `origins` (this rank's range, reference order) when the slide is not resident: the tiles are
     grouped by tile row; the P-row strip of each group is read from the reader into a pinned buffer, uploaded
-    on a side stream (two strip buffers: the upload of strip k+1 runs under the forward of strip k) and
+    on a side stream (two strip buffers: the disk read and the upload of strip k+1 run under the forward of strip k) and
     serves as the 'slide' of dh_resnet18_forward_tiles; logits land at their reference-order positions."""
     dev, P, w = sampler.device, sampler.patch_size, sampler.w
     main = torch.cuda.current_stream(dev)
@@ -249,8 +249,6 @@ def _forward_streamed(sampler, handle, origins: np.ndarray, local: torch.Tensor,
     for k, idx in enumerate(groups):
         b = k & 1
         main.wait_event(uploaded[b])
-        if k + 1 < len(ys):
-            stage(k + 1)
         o = np.zeros((len(idx), 2), np.int32)
         o[:, 1] = origins[idx, 1]
         o_dev = torch.from_numpy(o).to(dev)
@@ -262,6 +260,10 @@ def _forward_streamed(sampler, handle, origins: np.ndarray, local: torch.Tensor,
         local[torch.from_numpy(idx).to(dev)] = out
         consumed[b] = torch.cuda.Event()
         consumed[b].record(main)
+        # strip k is queued: NOW read strip k+1 from the reader (the host blocks on the disk while the GPU runs strip k;
+        # staging before the launches left the GPU idle during every read)
+        if k + 1 < len(ys):
+            stage(k + 1)
 
 
 def perform_and_save_visualizations(img, anno_dsc, pred, out_dir: Path = Path("."), stem: str | None = None,

@@ -55,6 +55,22 @@ def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+def ce_loss(logits: torch.Tensor, labels: torch.Tensor, want_grad: bool = False):
+    """Mean cross entropy of float32[n, n_cls] logits against int64 labels on the GPU (`dh_ce_loss`:
+    nn.CrossEntropyLoss() of train.py:117).  Returns the scalar loss tensor, or (loss, dlogits) with
+    dlogits = (softmax - onehot) / n when `want_grad`."""
+    if not logits.is_cuda:
+        raise RuntimeError("ce_loss runs on the GPU only")
+    logits = logits.detach().to(torch.float32).contiguous()
+    labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    st = C.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
+    check(lib().dh_ce_loss(logits.data_ptr(), labels.data_ptr(), logits.shape[0], logits.shape[1], loss.data_ptr(),
+                           dl.data_ptr() if want_grad else None, st), "dh_ce_loss")
+    return (loss, dl) if want_grad else loss
+
+
 class _TrainForward(torch.autograd.Function):
     """logits = model(x) in training mode; backward runs the HIP backward kernels and hands
     every parameter its gradient (so `loss.backward(); optimizer.step()` of

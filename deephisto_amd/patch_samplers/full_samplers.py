@@ -188,10 +188,27 @@ class FullImageRndSampler(_SlideHolder):
             yield [DevicePatch(self.layer, int(x), int(y), self.patch_size, self) for y, x in origins], filled
 
     def generator_torch(self) -> Iterator[tuple[torch.Tensor, torch.Tensor, float]]:
+        """(features f32[B,P,P,3] with the RAW 0..255 values -- no /255 here, full_samplers.py:286 --,
+        coords f32[B,2] (y,x), filled ratio)."""
+        P = self.patch_size
+        if not self.resident:
+            # ONDISK_MULTIPROC (full_samplers.py:237-262 reads every patch from the file): the batch's patches go from
+            # the open reader into one pinned staging image [B*P, P, 3] and are cut from it on the GPU
+            for origins, filled in self._origin_batches():
+                B = len(origins)
+                pinned = torch.empty((B * P, P, 3), dtype=torch.uint8).pin_memory()
+                buf = pinned.numpy()
+                for j, (y, x) in enumerate(origins):
+                    buf[j * P:(j + 1) * P] = self.read_region(int(y), int(x), int(y) + P, int(x) + P)
+                img = pinned.to(self.device, non_blocking=True)
+                so = torch.stack([torch.arange(B, dtype=torch.int32) * P, torch.zeros(B, dtype=torch.int32)], 1).to(self.device)
+                o_dev = torch.tensor(np.asarray(origins), dtype=torch.int32, device=self.device)
+                yield tiles.gather_tiles_raw(img, so, P), tiles.tile_coords(o_dev), filled
+            return
         slide = self.data_device
         for origins, filled in self._origin_batches():
             o_dev = torch.tensor(origins, dtype=torch.int32, device=slide.device)
-            yield tiles.gather_tiles_raw(slide, o_dev, self.patch_size), tiles.tile_coords(o_dev), filled
+            yield tiles.gather_tiles_raw(slide, o_dev, P), tiles.tile_coords(o_dev), filled
 
 
 class FullImageDenseSampler(_SlideHolder):
@@ -270,11 +287,11 @@ class FullImageDenseSampler(_SlideHolder):
         for i in range(nb):
             k = i & 1
             torch.cuda.current_stream(dev).wait_event(ready[k])
-            if i + 1 < nb:
-                stage(i + 1)                     # read ahead into the other buffer while batch i is consumed
-            yield staged[k], so, i
+            yield staged[k], so, i               # the consumer queues its kernels on batch i
             consumed[k] = torch.cuda.Event()
             consumed[k].record(torch.cuda.current_stream(dev))
+            if i + 1 < nb:
+                stage(i + 1)                     # only now read ahead: the GPU is busy with batch i during the disk read
 
     def generator_device(self, layout: int = DH_LAYOUT_NCHW, dtype=torch.float32
                          ) -> Iterator[tuple[torch.Tensor, np.ndarray, float]]:

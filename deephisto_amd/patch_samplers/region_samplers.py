@@ -277,10 +277,29 @@ class _SlideBank:
         self._dev = [s.to(device).contiguous() if isinstance(s, torch.Tensor) else None for s in sources]
         self.layer, self.device = layer, torch.device(device)
 
-    def host_patch(self, j: int, y: int, x: int, ps: int):
+    def size(self, j: int) -> tuple[int, int]:
         if self._readers[j] is None:
-            return self._dev[j][y:y + ps, x:x + ps, :].cpu().numpy()
-        return self._readers[j].get_region_from_layer(self.layer, (y, x), (y + ps, x + ps))
+            return int(self._dev[j].shape[0]), int(self._dev[j].shape[1])
+        return tuple(self._readers[j].layer_size(self.layer))
+
+    def host_patch(self, j: int, y: int, x: int, ps: int):
+        """uint8[ps, ps, 3] at (y, x).  The reference's origin bounds (region_samplers.py:112-118, 160-166)
+        let a patch hang over the image border; what psimage returns there is outside this repository, here
+        the pixels outside the image are 0 -- the same rule as the device gather (dh_tile_gather_aug)."""
+        h, w = self.size(j)
+        ya, yb, xa, xb = max(y, 0), min(y + ps, h), max(x, 0), min(x + ps, w)
+        inside = ya == y and xa == x and yb == y + ps and xb == x + ps
+        if yb <= ya or xb <= xa:
+            return np.zeros((ps, ps, 3), np.uint8)
+        if self._readers[j] is None:
+            part = self._dev[j][ya:yb, xa:xb, :].cpu().numpy()
+        else:
+            part = np.asarray(self._readers[j].get_region_from_layer(self.layer, (ya, xa), (yb, xb)))
+        if inside:
+            return part
+        out = np.zeros((ps, ps, 3), np.uint8)
+        out[ya - y:yb - y, xa - x:xb - x, :] = part
+        return out
 
     def slide(self, j: int) -> torch.Tensor:
         if self._dev[j] is None:
@@ -502,5 +521,7 @@ class AnnoRegionDenseSampler:
                 for k in range(0, len(coords), batch_size):
                     o = np.array(coords[k:k + batch_size], dtype=np.int32)
                     o_dev = torch.from_numpy(o).to(dev)
-                    x = tiles.gather_tiles(self._bank.slide(region.image_index), o_dev, ps, layout, dtype, check_bounds=False)
+                    # bounds-safe gather (zero outside the image): dense origins of a region that touches or leaves
+                    # the image border can be negative or hang over it (region_samplers.py:160-166)
+                    x = tiles.gather_tiles_aug(self._bank.slide(region.image_index), o_dev, ps, layout, dtype)
                     yield x, torch.full((len(o),), cls_idx, dtype=torch.int64, device=dev), tiles.tile_coords(o_dev)

@@ -77,13 +77,15 @@ int dh_tile_gather(const uint8_t* slide_dev, int64_t h, int64_t w, const int32_t
  * (models/patch_cls_simple/train.py:71-81: permute to NCHW, then RandomHorizontalFlip /
  * RandomVerticalFlip applied to the whole batch, i.e. one coin per batch): flip_h mirrors
  * columns, flip_v mirrors rows of every tile.  Feeds the a9 output contract
- * (patch_samplers/region_samplers.py:616-621, 729-738). */
+ * (patch_samplers/region_samplers.py:616-621, 729-738).  Origins may lie partly or wholly outside the
+ * slide (the region samplers' origin bounds, region_samplers.py:112-118, allow a patch to hang over the
+ * border): pixels outside [0,h) x [0,w) are written as 0, nothing outside the slide is read. */
 int dh_tile_gather_aug(const uint8_t* slide_dev, int64_t h, int64_t w, const int32_t* yx_dev,
                        int64_t n, int32_t patch, int32_t layout, int32_t dtype, int32_t flip_h,
                        int32_t flip_v, void* out_dev, void* stream);
 
 /* FullImageRndSampler.generator_torch (full_samplers.py:277-290) stacks the uint8 patches into a
- * float tensor WITHOUT dividing by 255: float32[n][P][P][3] with values 0..255. */
+ * float tensor WITHOUT dividing by 255: float32[n][P][P][3] with values 0..255 (0 outside the slide). */
 int dh_tile_gather_raw(const uint8_t* slide_dev, int64_t h, int64_t w, const int32_t* yx_dev,
                        int64_t n, int32_t patch, float* out_dev, void* stream);
 

@@ -156,3 +156,83 @@ def test_anno_region_sampler_device_batches(dev):
         loss, _ = model.train_step(xb, yb, lr=1e-3)
         losses.append(float(loss))
     assert all(np.isfinite(losses))
+
+
+def test_border_regions_zero_filled_on_device(dev):
+    """Regions touching / leaving the image border: the device gather writes 0 for pixels outside the
+    slide and reads nothing outside it; batches equal the host records of tests/test_region_borders.py."""
+    from deephisto_amd.patch_samplers.region_samplers import AnnoRegionDenseSampler, AnnoRegionRndSampler
+    img = synth.synth_slide(700, 1000, 5)
+
+    def expected(y, x, ps):
+        out = np.zeros((ps, ps, 3), np.uint8)
+        ya, yb, xa, xb = max(y, 0), min(y + ps, 700), max(x, 0), min(x + ps, 1000)
+        if yb > ya and xb > xa:
+            out[ya - y:yb - y, xa - x:xb - x] = img[ya:yb, xa:xb]
+        return out.astype(np.float32) / 255
+
+    anno = [{"class": "TUM", "vertices": [[790, 50], [1000, 50], [1000, 650], [790, 650]]},
+            {"class": "BG", "vertices": [[-50, -30], [400, -30], [400, 380], [-50, 380]]}]
+    smp = AnnoRegionRndSampler([(img, anno)], layer=1, patch_size=256, region_intersection=0.5, device=dev)
+    np.random.seed(3)
+    recs = smp._records(16)
+    assert any(x + 256 > 1000 for _, _, x, _ in recs) and any(y < 0 or x < 0 for _, y, x, _ in recs)
+    np.random.seed(3)
+    f, lab, c = next(smp.torch_generator(batch_size=16, n_batches=1))
+    for i, (_, y, x, cls) in enumerate(recs):
+        np.testing.assert_array_equal(f[i].cpu().numpy(), expected(y, x, 256))
+    dense = AnnoRegionDenseSampler([(img, anno)], layer=1, patch_size=128, stride=64, device=dev)
+    n = 0
+    for x, lab, c in dense.device_batches(16, layout=0):
+        for i in range(x.shape[0]):
+            np.testing.assert_array_equal(x[i].cpu().numpy(), expected(int(c[i, 0]), int(c[i, 1]), 128))
+            n += 1
+    assert n > 0
+
+
+def test_reference_caller_shape_through_aliases(dev, tmp_path):
+    """The dense branch of the reference's `__main__` (examples/predict_full_patched.py:128-177) written against
+    the reference's module paths: load_model from a state_dict file, FullImageDenseSampler(img, layer, patch_size,
+    batch_size, stride), ImagePredictorPatched(..., patch_sampler=sampler.generator(), batch_predictor=lambda ...),
+    process(), perform_and_save_visualizations."""
+    import deephisto_amd
+    deephisto_amd.install_aliases(force=True)
+    try:
+        from anno.utils import AnnoDescription
+        from examples.predict_full_patched import (ImagePredictorPatched, batch_predictor, load_model,
+                                                   perform_and_save_visualizations)
+        from models.patch_cls_simple import utils
+        from models.patch_cls_simple.model import get_model
+        from patch_samplers.full_samplers import FullImageDenseSampler
+
+        ref = oracle_net.seeded_model(2, 5, perturb_bn=True).eval()
+        torch.save(ref.state_dict(), tmp_path / "best_model.pth")
+        img_path = tmp_path / "test_01.npy"
+        host = synth.synth_slide(900, 1100, 8)
+        np.save(img_path, host)
+
+        device = utils.get_device()
+        model = load_model(tmp_path / "best_model.pth", device)
+        anno_dsc = AnnoDescription.with_known_colors({"AT": (245, 119, 34), "BG": (153, 255, 255), "LP": (64, 170, 72),
+                                                      "MM": (255, 0, 0), "TUM": (33, 67, 156)})
+        layer, downscale_vis = 1, 16
+        patch_sampler = FullImageDenseSampler(img_path, layer=layer, patch_size=224, batch_size=8, stride=112)
+        predictor = ImagePredictorPatched(img_path, patch_sampler=patch_sampler.generator(),
+                                          batch_predictor=lambda patches: batch_predictor(patches, model, device),
+                                          anno=anno_dsc, layer=layer, downscale=downscale_vis)
+        pred = predictor.process()
+        assert pred.dtype == np.int64 and pred.shape == (900 // 16, 1100 // 16)
+        # against the oracle pipeline on the same tiles
+        o = tiling.batched_origins(900, 1100, 224, 112, 8).reshape(-1, 2)
+        with torch.no_grad():
+            logits = ref(torch.from_numpy(tiling.features_nchw_predictor(host, o, 224))).numpy()
+        canvas = tiling.accumulate_logits(900, 1100, 5, 16, 224, o, logits)
+        want = tiling.class_map(canvas)
+        top2 = np.sort(canvas, axis=2)
+        decided = (top2[..., -1] - top2[..., -2]) > 1e-3
+        assert np.array_equal(pred[decided], want[decided])
+        mask, small, ov = perform_and_save_visualizations(img_path, anno_dsc, pred, out_dir=tmp_path / "output")
+        assert (tmp_path / "output" / "test_01_mask.jpg").exists() and mask.shape == pred.shape + (3,)
+        assert get_model(5).__class__.__name__ == model.__class__.__name__
+    finally:
+        deephisto_amd.uninstall_aliases()
