@@ -21,6 +21,7 @@ DH_LAYOUT_NHWC, DH_LAYOUT_NCHW = 0, 1
 DH_DTYPE_F32, DH_DTYPE_BF16 = 0, 1
 
 _i32, _i64, _u32 = C.c_int32, C.c_int64, C.c_uint32
+BUCKET_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int64, C.c_int64, C.c_void_p)   # dh_bucket_cb
 _p = C.c_void_p
 
 # name -> (restype, argtypes); must list every symbol of include/deephisto_hip.h
@@ -53,6 +54,18 @@ SIGNATURES = {
     "dh_resnet18_train_tensor": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _i32, _p]),
     "dh_resnet18_train_repack": (C.c_int, [_p, _p]),
     "dh_resnet18_train_flat": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),
+    "dh_resnet18_set_buckets": (C.c_int, [_p, _i64, _p, _p, C.POINTER(_i32)]),
+    "dh_resnet18_bucket": (C.c_int, [_p, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "dh_train2_create": (C.c_int, [C.POINTER(_p), C.c_char_p, _i32]),
+    "dh_train2_destroy": (None, [_p]),
+    "dh_train2_tensor": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _i32, _p]),
+    "dh_train2_flat": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),
+    "dh_train2_set_buckets": (C.c_int, [_p, _i64, _p, _p, C.POINTER(_i32)]),
+    "dh_train2_bucket": (C.c_int, [_p, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "dh_train2_forward": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p]),
+    "dh_train2_backward": (C.c_int, [_p, _p, _p]),
+    "dh_train2_adam_step": (C.c_int, [_p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
+    "dh_train2_debug_act": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _p]),
     "dh_debug_conv_bn_act": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i32] * 9 + [_p]),
     "dh_debug_stem_out": (C.c_int, [_p, _i64, _i32, _p, _p]),
     "dh_debug_stamps": (C.c_int, [_i32, _p]),

@@ -1257,3 +1257,5 @@ extern "C" int dh_debug_stamps(int32_t enable, unsigned long long* out64_host) {
 }
 
 #include "train.inc"
+#include "train2_kernels.inc"
+#include "train2.inc"

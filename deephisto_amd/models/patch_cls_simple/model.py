@@ -18,7 +18,8 @@ import ctypes as C
 import torch
 import torch.nn as nn
 
-from ..._lib import DH_DTYPE_BF16, DH_DTYPE_F32, check, lib
+from ..._lib import BUCKET_CB, DH_DTYPE_BF16, DH_DTYPE_F32, check, lib
+from .ddp import DEFAULT_BUCKET_BYTES, BucketReducer, allreduce_mean_  # noqa: F401  (allreduce_mean_ re-exported)
 
 _STAGES = ((64, 1), (128, 2), (256, 2), (512, 2))
 
@@ -40,19 +41,6 @@ class _DevView:
 
     def __init__(self, ptr: int, n: int):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-
-def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
-    """In-place mean of `flat` over the ranks of `group` (data-parallel gradient exchange).
-    One collective over the whole 44.7 MB gradient arena: RCCL all-reduce on GPUs
-    (backend "nccl"); identical code path on gloo in the CPU tests."""
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    if world > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.div_(world)
-    return flat
 
 
 def ce_loss(logits: torch.Tensor, labels: torch.Tensor, want_grad: bool = False):
@@ -112,6 +100,7 @@ class ResNet18HIP(nn.Module):
         self._handle = None
         self._synced = None  # signature of the parameter versions held by the handle
         self._lanes = []     # extra native handles (own workspace each) for multi-stream inference
+        self._engine2 = None  # bf16 training engine (dh_train2), created on the first bf16 training forward
 
     # ---- native handle management -------------------------------------------------
     def _signature(self):
@@ -172,6 +161,9 @@ class ResNet18HIP(nn.Module):
             if lane[0]:
                 lib().dh_resnet18_destroy(lane[0])
         self._lanes = []
+        if getattr(self, "_engine2", None) is not None:
+            self._engine2.release()
+            self._engine2 = None
 
     def __del__(self):
         try:
@@ -188,9 +180,13 @@ class ResNet18HIP(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3]:
             raise ValueError(f"expected [n, 3, P, P], got {tuple(x.shape)}")
         x = x.detach().to(torch.float32).contiguous()
+        if self.training and self.compute_dtype == "bf16":   # bf16 activations / MFMA, f32 masters: the dh_train2 engine
+            e2 = self._bf16_engine()
+            e2.pull_parameters()
+            if torch.is_grad_enabled():
+                return _TrainForward2.apply(x, e2, *self.parameters())
+            return e2.forward(x, True)
         if self.training:
-            if self.compute_dtype != "f32":
-                raise NotImplementedError("training kernels are float32 only in this build")
             if torch.is_grad_enabled():
                 return _TrainForward.apply(x, self, *self.parameters())
             return self._native_forward_train(x)  # e.g. train-mode forward under no_grad
@@ -200,6 +196,11 @@ class ResNet18HIP(nn.Module):
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         check(lib().dh_resnet18_forward(h, x.data_ptr(), n, p, out.data_ptr(), stream), "dh_resnet18_forward")
         return out
+
+    def _bf16_engine(self):
+        if self._engine2 is None:
+            self._engine2 = Train2Engine(self, "resnet18", self.n_classes)
+        return self._engine2
 
     # ---- training (row a7): HIP forward/backward behind torch autograd ---------------------
     def _stream(self, dev):
@@ -271,15 +272,19 @@ class ResNet18HIP(nn.Module):
         check(lib().dh_resnet18_train_flat(self._handle, 1, C.byref(ptr), C.byref(n)), "dh_resnet18_train_flat")
         return torch.as_tensor(_DevView(ptr.value, n.value), device=device)
 
-    def train_step(self, x, labels, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None):
+    def train_step(self, x, labels, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
         """Fused step entirely in HIP: forward, CrossEntropy(mean), backward, Adam.
-        Under torch.distributed (one process per GPU) the gradients are averaged over `group`
-        with one all-reduce of the flat gradient arena between backward and Adam (DDP
-        semantics: per-rank batch statistics, replicas stay identical).
+        Under torch.distributed (one process per GPU) the gradients are averaged over `group`: the arena is cut
+        into ~`bucket_bytes` buckets in backward-completion order and each bucket's all-reduce starts on a side
+        stream as soon as its last wgrad is enqueued (models/patch_cls_simple/ddp.py); Adam waits for the last
+        one (DDP semantics: per-rank batch statistics, replicas stay identical).
         Returns (loss tensor on device, logits).  nn.Parameters are refreshed lazily by
         `pull_parameters()` / state_dict()."""
         if not self.training:
             raise RuntimeError("train_step needs .train() mode")
+        if self.compute_dtype == "bf16":
+            self._synced = None   # the eval-mode copy of the parameters must be rebuilt after this update
+            return self._bf16_engine().train_step(x, labels, lr, betas, eps, group)
         x = x.detach().to(torch.float32).contiguous()
         labels = labels.to(device=x.device, dtype=torch.int64).contiguous()
         logits = self._native_forward_train(x, pull_stats=False)   # 40 small copies per step otherwise; pulled lazily
@@ -288,10 +293,17 @@ class ResNet18HIP(nn.Module):
         dl = torch.empty_like(logits)
         check(lib().dh_ce_loss(logits.data_ptr(), labels.data_ptr(), logits.shape[0], self.n_classes, loss.data_ptr(),
                                dl.data_ptr(), st), "dh_ce_loss")
-        check(lib().dh_resnet18_backward(self._handle, dl.data_ptr(), st), "dh_resnet18_backward")
         import torch.distributed as dist
+        red = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            allreduce_mean_(self.flat_gradients(x.device), group)
+            red = BucketReducer(self.flat_gradients(x.device), group)
+            cb = BUCKET_CB(lambda bucket, off, cnt, _user: red.on_bucket(bucket, off, cnt))
+            check(lib().dh_resnet18_set_buckets(self._handle, int(bucket_bytes), cb, None, None), "dh_resnet18_set_buckets")
+        check(lib().dh_resnet18_backward(self._handle, dl.data_ptr(), st), "dh_resnet18_backward")
+        if red is not None:
+            red.finish()
+            self.overlap_log = red.log
+            check(lib().dh_resnet18_set_buckets(self._handle, 0, None, None, None), "dh_resnet18_set_buckets")
         self._adam_t = getattr(self, "_adam_t", 0) + 1
         check(lib().dh_resnet18_adam_step(self._handle, lr, betas[0], betas[1], eps, self._adam_t, st), "dh_resnet18_adam_step")
         self._native_ahead = True
@@ -299,6 +311,8 @@ class ResNet18HIP(nn.Module):
 
     def pull_parameters(self):
         """Library masters and running statistics -> nn.Parameters / buffers (after fused train_step calls)."""
+        if self._engine2 is not None:
+            self._engine2.pull_parameters()
         self._pull_running_stats()
         if getattr(self, "_native_ahead", False):
             with torch.no_grad():
@@ -336,6 +350,14 @@ class ResNet18HIP(nn.Module):
         return out
 
 
-def get_model(n_classes: int, compute_dtype: str = "f32") -> ResNet18HIP:
-    """Same call as the reference's `get_model(n_classes)` (model.py:5)."""
-    return ResNet18HIP(n_classes, compute_dtype)
+def get_model(n_classes: int, compute_dtype: str = "f32", arch: str = "resnet18") -> nn.Module:
+    """Same call as the reference's `get_model(n_classes)` (model.py:5).  `arch="resnet50"` selects the ResNet-50
+    backbone of BASELINE.json configs[4] (bf16 engine, whatever `compute_dtype` says)."""
+    if arch == "resnet18":
+        return ResNet18HIP(n_classes, compute_dtype)
+    if arch == "resnet50":
+        return ResNet50HIP(n_classes)
+    raise ValueError(f"unknown architecture {arch!r} (resnet18, resnet50)")
+
+
+from .resnet_bf16 import ResNet50HIP, Train2Engine, _TrainForward2  # noqa: E402  (needs ce_loss above)

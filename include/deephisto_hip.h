@@ -184,6 +184,45 @@ int dh_resnet18_train_repack(dh_resnet18* net, void* stream);
 /* Device pointer + element count of a whole arena (kind as above): data-parallel training
  * all-reduces the gradient arena in place (RCCL) between backward and adam_step. */
 int dh_resnet18_train_flat(dh_resnet18* net, int32_t kind, void** ptr_out, int64_t* n_out);
+/* Gradient buckets for the overlapped all-reduce of data-parallel training: the gradient arena is cut
+ * into buckets of about bucket_bytes (0 = one) in the order the backward pass completes them (from the END of the arena:
+ * fc, layer4 ... layer1, stem); `cb(bucket, offset, count, user)` is called on the calling thread from inside
+ * dh_resnet18_backward as soon as the kernels that complete a bucket are enqueued. */
+int dh_resnet18_set_buckets(dh_resnet18* net, int64_t bucket_bytes,
+                            void (*cb)(int32_t bucket, int64_t offset, int64_t count, void* user), void* user,
+                            int32_t* n_buckets_out);
+int dh_resnet18_bucket(dh_resnet18* net, int32_t i, int64_t* offset, int64_t* count);
+
+/* ---- configs[4]: ResNet-50 (and ResNet-18) training / evaluation in bf16 ---------------------------
+ * The same step (models/patch_cls_simple/train.py:166-172; CrossEntropyLoss(mean) :117, Adam :118) for the network the
+ * factory of models/patch_cls_simple/model.py:5-11 returns when it is given a ResNet-50 backbone (BASELINE.json
+ * configs[4]: torchvision resnet50 v1.5 + fc[n_cls, 2048]; "resnet18" selects the reference's own backbone).
+ * Activations and their gradients are bf16 (bf16 MFMA, f32 accumulation: forward, dgrad AND wgrad); master weights,
+ * gradients, Adam moments and BN statistics are float32.  Parameters are set / read by torchvision state_dict name
+ * with dh_train2_tensor (kind 0 parameter, 1 gradient, 2 running statistic; host or device pointers).
+ *   forward(training != 0): batch-statistic BN, running statistics updated; x_dev float32[n][3][P][P] must stay alive
+ *                           until backward.  forward(training == 0): BN from the running statistics (evaluation).
+ *   backward              : dlogits float32[n][n_classes] -> every gradient (no float atomics: reproducible)
+ *   adam_step             : step <= 0 uses the library's own step count
+ *   set_buckets           : cut the gradient arena (laid out in backward-completion order, fc first) into buckets of about
+ *                           bucket_bytes; `cb` is called on the calling thread inside backward as soon as the kernels that
+ *                           complete a bucket are enqueued -- the hook for the bucketed, overlapped RCCL all-reduce of
+ *                           data-parallel training.  dh_train2_bucket returns a bucket's element range. */
+typedef struct dh_train2 dh_train2;
+typedef void (*dh_bucket_cb)(int32_t bucket, int64_t offset, int64_t count, void* user);
+int dh_train2_create(dh_train2** out, const char* arch, int32_t n_classes);
+void dh_train2_destroy(dh_train2* net);
+int dh_train2_tensor(dh_train2* net, const char* name, int32_t kind, void* ptr, int64_t n_elem, int32_t to_lib,
+                     void* stream);
+int dh_train2_flat(dh_train2* net, int32_t kind, void** ptr_out, int64_t* n_out);
+int dh_train2_set_buckets(dh_train2* net, int64_t bucket_bytes, dh_bucket_cb cb, void* user, int32_t* n_buckets_out);
+int dh_train2_bucket(dh_train2* net, int32_t i, int64_t* offset, int64_t* count);
+int dh_train2_forward(dh_train2* net, const float* x_dev, int64_t n, int32_t patch, float* logits_dev,
+                      int32_t training, void* stream);
+int dh_train2_backward(dh_train2* net, const float* dlogits_dev, void* stream);
+int dh_train2_adam_step(dh_train2* net, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+/* test hook: float32 copy of conv `conv_name`'s raw output (what = 0) or BN/ReLU output (what = 1) of the last forward */
+int dh_train2_debug_act(dh_train2* net, const char* conv_name, int32_t what, float* out_dev, int64_t n_elem, void* stream);
 
 /* ---- debug / test hooks (not part of the drop-in boundary) ---------------------
  * dh_debug_conv_bn_act: one conv (ks in {1,3}, pad ks/2) + per-channel scale/shift

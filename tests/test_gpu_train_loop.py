@@ -175,10 +175,10 @@ def test_border_regions_zero_filled_on_device(dev):
             {"class": "BG", "vertices": [[-50, -30], [400, -30], [400, 380], [-50, 380]]}]
     smp = AnnoRegionRndSampler([(img, anno)], layer=1, patch_size=256, region_intersection=0.5, device=dev)
     np.random.seed(3)
-    recs = smp._records(16)
+    recs = smp._records(32)
     assert any(x + 256 > 1000 for _, _, x, _ in recs) and any(y < 0 or x < 0 for _, y, x, _ in recs)
     np.random.seed(3)
-    f, lab, c = next(smp.torch_generator(batch_size=16, n_batches=1))
+    f, lab, c = next(smp.torch_generator(batch_size=32, n_batches=1))
     for i, (_, y, x, cls) in enumerate(recs):
         np.testing.assert_array_equal(f[i].cpu().numpy(), expected(y, x, 256))
     dense = AnnoRegionDenseSampler([(img, anno)], layer=1, patch_size=128, stride=64, device=dev)
