@@ -3,7 +3,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import synth
+from oracle import resnet18 as oracle_net
+from oracle import synth, tiling
 
 pytestmark = pytest.mark.gpu
 
