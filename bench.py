@@ -13,10 +13,17 @@ ordered accumulate + argmax produce the int64 class map.  The slide is generated
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+Rank 0 prints ONE JSON line (contract in the task description) with extra objects:
 `roofline` for the dominant kernel (3x3 stride-1 conv, MFMA-bound) timed live with HIP
-events on the launch stream, and `cpu_baseline`: the oracle's CPU restatement of the
-reference path (NumPy tiling + torch-CPU ResNet-18 fp32) timed on a bounded sample.
+events on the launch stream; `cpu_baseline`: the oracle's CPU restatement of the reference
+path (NumPy tiling + torch-CPU ResNet-18 fp32) timed on a bounded sample; and, at N = 1,
+  `f32`        the same slide in float32 (the mode of north_star's "logits within 1e-4"), its own roofline vs 157.3 TF;
+  `train`      BASELINE configs[1]: fused ResNet-18 f32 training steps/s at 64 x 224^2, with a roofline object;
+  `train_r50`  BASELINE configs[4] per-rank work: ResNet-50 bf16 training steps/s at 64 x 224^2 vs the bf16 MFMA peak;
+  `tiler`      the stand-alone gather kernels (a4 path) in GB/s against the 8 TB/s HBM peak;
+  `cpu_baselines` sampler-only `generator_torch` (one process, as INMEMORY_SINGLEPROC) and a CPU train step, each with cores.
+At N > 1 the line also carries `train_ddp`: ResNet-50 bf16 data-parallel steps/s with the bucketed, overlapped RCCL
+all-reduce (configs[4]); a failure there is reported in the object and never costs the headline number.
 """
 from __future__ import annotations
 
@@ -55,7 +62,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10,
-                    help="extra leg: time this many fused training steps (BASELINE configs[1]); 0 = skip")
+                    help="extra legs: time this many fused training steps (configs[1] f32 ResNet-18, configs[4] bf16 ResNet-50); 0 = skip")
+    ap.add_argument("--f32-steps", type=int, default=2, help="extra leg: whole slides in float32 (0 = skip)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline measurement only (profiling runs)")
     return ap.parse_args()
 
 
@@ -102,33 +111,127 @@ def cpu_baseline(args, budget_s: float) -> dict:
                       f"ResNet-18 eager, {threads} threads, {dt:.1f} s"}
 
 
-def train_leg(dev, steps: int) -> dict:
-    """BASELINE configs[1]: models.patch_cls_simple.train step on synthetic annotated regions,
-    1 GPU, fp32: batch 64 x 3 x 224 x 224 (config.yaml), HIP forward + CE + backward + Adam."""
+ADAM_BYTES_R18 = 7 * 11_179_077 * 4   # read p, g, m, v + write p, m, v (~313 MB per step)
+
+
+def train_leg(dev, steps: int, arch: str = "resnet18", dtype: str = "f32", group=None) -> dict:
+    """Fused training steps (forward + CrossEntropy + backward [+ bucketed all-reduce] + Adam, all HIP) on synthetic
+    annotated regions, batch 64 x 3 x 224 x 224 per rank (config.yaml), data assembly (gather + /255 + flips) included.
+    resnet18 / f32 = BASELINE configs[1]; resnet50 / bf16 = configs[4] (per-rank work; `group` set => data parallel)."""
     from deephisto_amd import tiles
     from deephisto_amd.models.patch_cls_simple.model import get_model
     from deephisto_amd.patch_samplers.region_samplers import RectRegionRndSampler, synthetic_regions
 
     side, B, P = 8192, 64, 224
+    rank = int(os.environ.get("RANK", "0"))
     slide = tiles.synth_slide(side, side, 1, dev)
-    smp = RectRegionRndSampler(slide, synthetic_regions(side, side, 5, seed=0), layer=1, patch_size=P, seed=0, device=dev)
+    smp = RectRegionRndSampler(slide, synthetic_regions(side, side, 5, seed=0), layer=1, patch_size=P, seed=rank, device=dev)
     torch.manual_seed(0)
-    model = get_model(5, "f32").to(dev).train()
+    model = get_model(5, dtype, arch=arch).to(dev).train()
     it = smp.device_batches(B, steps + 2, flips=True)
     for _ in range(2):
         x, y, _c = next(it)
-        model.train_step(x, y, lr=1e-4)
+        model.train_step(x, y, lr=1e-4, group=group)
     torch.cuda.synchronize(dev)
+    if group is not None:
+        import torch.distributed as dist
+        dist.barrier()
     t0 = time.perf_counter()
     for x, y, _c in it:
-        loss, _ = model.train_step(x, y, lr=1e-4)
+        loss, _ = model.train_step(x, y, lr=1e-4, group=group)
     torch.cuda.synchronize(dev)
+    if group is not None:
+        dist.barrier()
     dt = time.perf_counter() - t0
-    return {"steps_per_s": steps / dt, "samples_per_s": steps * B / dt, "ms_per_step": 1e3 * dt / steps,
-            "config": {"workload": "BASELINE configs[1]: train step (fwd + CrossEntropy + bwd + Adam, HIP) on synthetic "
-                                   "annotated regions, data assembly (gather + /255 + flips) included",
-                       "batch": B, "patch": P, "dtype": "f32", "steps": steps, "last_loss": float(loss)},
-            "model_tflops": steps * B * 3 * 3.6271e9 / dt / 1e12}
+    world = 1 if group is None else dist.get_world_size(group)
+    fwd_flop = (3.6271e9 if arch == "resnet18" else 8.1743e9)    # per 224^2 sample (SURVEY section 8d)
+    tflops = world * steps * B * 3 * fwd_flop / dt / 1e12        # train step counted as 3 x forward
+    peak = MFMA_PEAK_TFLOPS[dtype] * world
+    out = {"steps_per_s": steps / dt, "samples_per_s": world * steps * B / dt, "ms_per_step": 1e3 * dt / steps,
+           "config": {"workload": f"train step (fwd + CrossEntropy + bwd + Adam, HIP) of {arch} in {dtype} on synthetic annotated "
+                                  "regions, data assembly (gather + /255 + flips) included",
+                      "arch": arch, "batch_per_rank": B, "patch": P, "dtype": dtype, "steps": steps, "ranks": world,
+                      "last_loss": float(loss)},
+           "model_tflops": tflops,
+           "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
+                        "flop_per_sample": 3 * fwd_flop,
+                        "note": "whole step (3 x forward FLOPs) over wall time, data assembly and optimizer included"}}
+    if arch == "resnet18":
+        out["roofline"]["adam_hbm_bytes_per_step"] = ADAM_BYTES_R18
+    if world > 1:
+        out["config"]["parallelism"] = f"dp{world}: bucketed (~25 MB) all-reduce overlapped with backward"
+        out["buckets"] = [c for _, _, c in getattr(getattr(model, "_engine", model), "overlap_log", [])]
+    return out
+
+
+def tiler_leg(dev, slide, args) -> dict:
+    """The stand-alone gather kernels (a4: generator_torch features NHWC f32; a5: batch_predictor input NCHW f32 / bf16):
+    algorithmic bytes per 256^2 tile = 196 608 read + 786 432 (f32) / 393 216 (bf16) written."""
+    from deephisto_amd import tiles
+    from deephisto_amd._lib import DH_LAYOUT_NCHW, DH_LAYOUT_NHWC
+
+    P, n = args.patch, 1024
+    g = torch.Generator().manual_seed(0)
+    o = torch.stack([torch.randint(0, slide.shape[0] - P, (n,), generator=g), torch.randint(0, slide.shape[1] - P, (n,), generator=g)], 1)
+    o = o.to(torch.int32).to(dev)
+    out = {}
+    for name, layout, dt in (("nhwc_f32", DH_LAYOUT_NHWC, torch.float32), ("nchw_f32", DH_LAYOUT_NCHW, torch.float32),
+                             ("nchw_bf16", DH_LAYOUT_NCHW, torch.bfloat16)):
+        tiles.gather_tiles(slide, o, P, layout, dt, check_bounds=False)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            tiles.gather_tiles(slide, o, P, layout, dt, check_bounds=False)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / 5
+        nbytes = n * (P * P * 3 + P * P * 3 * (4 if dt == torch.float32 else 2))
+        out[name] = {"tiles_per_s": n / (ms * 1e-3), "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0, "bytes_per_tile": nbytes // n}
+    return {"bound": "hbm", "tiles_per_launch": n, "patch": P, "kernels": out}
+
+
+def cpu_sampler_baseline(args, budget_s: float) -> dict:
+    """the oracle's restatement of FullImageDenseSampler.generator_torch
+    (full_samplers.py:437-452: stack -> astype(f32)/255 -> torch.tensor, coords) in ONE process, as INMEMORY_SINGLEPROC."""
+    from oracle import synth, tiling
+
+    torch.set_num_threads(1)
+    side = 4096
+    host = synth.synth_slide(side, side, args.seed)
+    batches = tiling.batched_origins(side, side, args.patch, args.stride, args.batch)
+    n, t0 = 0, time.perf_counter()
+    for ob in batches:
+        f = torch.tensor(tiling.features_nhwc(host, ob, args.patch))
+        c = torch.tensor(ob.astype(np.float32))
+        n += len(ob)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    del f, c
+    return {"value": n / dt, "unit": "patches/s", "cores": 1, "kind": "port",
+            "sample": f"{n} tiles of a {side}x{side} closed-form slide, patch {args.patch}, batch {args.batch}, one process, {dt:.1f} s"}
+
+
+def cpu_train_baseline(steps: int) -> dict:
+    """torch-CPU eager ResNet-18 restatement, CrossEntropyLoss, Adam(lr=1e-4), all cores."""
+    from oracle import resnet18 as oracle_net
+
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    net = oracle_net.seeded_model(0, 5).train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(64, 3, 224, 224, generator=g)
+    y = torch.randint(0, 5, (64,), generator=g)
+    oracle_net.train_step(net, opt, x, y)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        oracle_net.train_step(net, opt, x, y)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} steps of batch 64 x 224^2, torch-CPU fp32 ResNet-18 eager + Adam, {threads} threads, {dt:.1f} s"}
 
 
 def main():
@@ -168,40 +271,54 @@ def main():
                                 stride=args.stride, device=dev)
     n_tiles = smp.n_tiles
 
-    def step():
-        return predict_full_patched(smp, model, 5, downscale=args.downscale, micro_batch=args.micro_batch,
-                                    streams=args.streams)
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # live timing of the dominant kernel over the timed region (every 4th launch sampled)
-    check(lib().dh_profile_start(4, 65536), "dh_profile_start")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cmap = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    k_ms, k_flops, k_n = C.c_double(), C.c_double(), C.c_int64()
-    check(lib().dh_profile_stop(C.byref(k_ms), C.byref(k_flops), C.byref(k_n)), "dh_profile_stop")
+    def timed_predict(mdl, steps, warmup):
+        """(elapsed seconds for `steps` whole slides, dominant-kernel ms / flops / samples over the timed region, class map)"""
+        def step():
+            return predict_full_patched(smp, mdl, 5, downscale=args.downscale, micro_batch=args.micro_batch, streams=args.streams)
+        for _ in range(warmup):
+            step()
+        fence()
+        # live timing of the dominant kernel over the timed region (every 4th launch sampled)
+        check(lib().dh_profile_start(4, 65536), "dh_profile_start")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cm = step()
+        fence()
+        el = time.perf_counter() - t0
+        k_ms, k_flops, k_n = C.c_double(), C.c_double(), C.c_int64()
+        check(lib().dh_profile_stop(C.byref(k_ms), C.byref(k_flops), C.byref(k_n)), "dh_profile_stop")
+        return el, k_ms.value, k_flops.value, int(k_n.value), cm
+
+    elapsed, k_ms_v, k_flops_v, k_n_v, cmap = timed_predict(model, args.steps, args.warmup)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     assert cmap.shape == (side // args.downscale, side // args.downscale)
 
+    # configs[4] under torch.distributed: ResNet-50 bf16 data-parallel steps (every rank takes part; reported by rank 0)
+    train_ddp = None
+    if world > 1 and args.train_steps > 0 and not args.no_extra_legs:
+        try:
+            del slide, smp
+            torch.cuda.empty_cache()
+            train_ddp = train_leg(dev, args.train_steps, "resnet50", "bf16", group=dist.group.WORLD)
+        except Exception as e:   # never costs the headline number
+            train_ddp = {"error": f"{type(e).__name__}: {e}"[:400]}
+
     if rank == 0:
         value = args.steps * n_tiles / elapsed
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        achieved = (k_flops.value / (k_ms.value * 1e-3)) / 1e12 if k_ms.value > 0 else 0.0
+        achieved = (k_flops_v / (k_ms_v * 1e-3)) / 1e12 if k_ms_v > 0 else 0.0
         flop_tile = FLOP_PER_TILE_256 * (args.patch / 256.0) ** 2
         traffic = None   # HBM bytes per launch of the dominant kernel: from the committed PMC passes (rocprofv3
-        pmc = REPO / "profiles" / "r01_pmc_dominant_kernel.json"   # cannot run inside the timed process)
+        pmc = next((q for q in (REPO / "profiles" / "r02_pmc_dominant_kernel.json", REPO / "profiles" / "r01_pmc_dominant_kernel.json")
+                    if q.exists()), REPO / "none")                  # cannot run inside the timed process)
         if pmc.exists() and args.dtype == "bf16" and args.patch == 256:
             doc = json.loads(pmc.read_text())
             if doc.get("micro_batch") == args.micro_batch:
@@ -224,16 +341,40 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<{args.dtype}, stride 1, NT=2, 8 waves> (layers 1-3, 10 of 20 convs; two instantiations: layer 1 keeps its weights resident in LDS)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "launches_timed": int(k_n.value),
-                         "avg_launch_us": 1e3 * k_ms.value / max(1, k_n.value),
-                         "flops_per_launch": k_flops.value / max(1, k_n.value)},
+                         "launches_timed": k_n_v,
+                         "avg_launch_us": 1e3 * k_ms_v / max(1, k_n_v),
+                         "flops_per_launch": k_flops_v / max(1, k_n_v)},
         }
-        if args.train_steps > 0 and world == 1:
+        extra = world == 1 and not args.no_extra_legs
+        if extra and args.f32_steps > 0 and args.dtype == "bf16":
+            # the configuration north_star's "logits within 1e-4 of the CPU reference" belongs to: same slide, float32 MFMA
+            m32 = get_model(5, "f32").to(dev).eval()
+            m32.load_state_dict(model.state_dict())
+            el, kms, kfl, kn, cm32 = timed_predict(m32, args.f32_steps, 1)
+            a32 = (kfl / (kms * 1e-3)) / 1e12 if kms > 0 else 0.0
+            v32 = args.f32_steps * n_tiles / el
+            out["f32"] = {"value": v32, "unit": "patches/s", "steps": args.f32_steps, "ms_per_step": 1e3 * el / args.f32_steps,
+                          "dtype": "f32", "model_tflops": v32 * flop_tile / 1e12,
+                          "class_map_agreement_with_bf16": float((cm32 == cmap).float().mean()),
+                          "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel<f32, stride 1, NT=2, 8 waves> (v_mfma_f32_32x32x2_f32)",
+                                       "achieved": a32, "peak": MFMA_PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                                       "frac": a32 / MFMA_PEAK_TFLOPS["f32"], "launches_timed": kn,
+                                       "avg_launch_us": 1e3 * kms / max(1, kn)}}
+            del m32
+        if extra:
+            out["tiler"] = tiler_leg(dev, slide, args)
+        if extra and args.train_steps > 0:
             del slide, smp
             torch.cuda.empty_cache()
-            out["train"] = train_leg(dev, args.train_steps)
+            out["train"] = train_leg(dev, args.train_steps, "resnet18", "f32")
+            out["train_r50"] = train_leg(dev, args.train_steps, "resnet50", "bf16")
+        if world > 1:
+            out["train_ddp"] = train_ddp
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+            if not args.no_extra_legs:
+                out["cpu_baselines"] = {"sampler_generator_torch": cpu_sampler_baseline(args, 4.0),
+                                        "train_step_resnet18_f32": cpu_train_baseline(2)}
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

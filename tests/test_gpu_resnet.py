@@ -135,8 +135,12 @@ def test_resnet18_bf16_logits(dev):
 
 def test_model_errors(dev):
     from deephisto_amd.models.patch_cls_simple.model import get_model
-    with pytest.raises(NotImplementedError):   # training kernels are float32 only
-        get_model(5, "bf16").to(dev).train()(torch.zeros(2, 3, 64, 64, device=dev))
+    out = get_model(5, "bf16").to(dev).train()(torch.rand(2, 3, 64, 64, device=dev))   # bf16 training: the dh_train2 engine
+    assert out.shape == (2, 5) and out.requires_grad
+    with pytest.raises(ValueError):
+        get_model(5, arch="resnet34")
+    with pytest.raises(Exception, match="P"):                                           # bf16 engine: 64 <= P <= 256
+        get_model(5, arch="resnet50").to(dev).train()(torch.zeros(1, 3, 288, 288, device=dev))
     m = get_model(5).to(dev)
     m.eval()
     with pytest.raises(RuntimeError, match="GPU only"):
