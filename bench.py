@@ -267,8 +267,10 @@ def main():
     slide = tiles.synth_slide(side, side, args.seed, dev)          # resident in HBM, untimed
     torch.manual_seed(0)
     model = get_model(5, args.dtype).to(dev).eval()                # seeded random init (no checkpoints offline)
-    smp = FullImageDenseSampler(slide, layer=1, patch_size=args.patch, batch_size=args.batch,
-                                stride=args.stride, device=dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # the sampler prints the slide size like the reference's constructor; stdout carries ONE JSON line
+        smp = FullImageDenseSampler(slide, layer=1, patch_size=args.patch, batch_size=args.batch,
+                                    stride=args.stride, device=dev)
     n_tiles = smp.n_tiles
 
     def fence():

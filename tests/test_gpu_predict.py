@@ -143,3 +143,69 @@ def test_ondisk_mode_streams_and_matches_resident(dev, tmp_path):
     cm_a, lg_a = predict_full_patched(res, model, 5, downscale=16, micro_batch=16, return_logits=True, streams=1)
     cm_b, lg_b = predict_full_patched(disk, model, 5, downscale=16, micro_batch=16, return_logits=True, streams=1)
     assert torch.equal(lg_a, lg_b) and torch.equal(cm_a, cm_b)
+
+
+def test_bf16_pipeline_class_map_gate(dev):
+    """SURVEY section 8d gate for the bf16 whole pipeline: predict_full_patched in bf16 on a 4096^2 closed-form slide
+    (256 tiles, BASELINE configs[0] geometry) against the float32 ORACLE pipeline on the CPU:
+      * per-tile logits within 3e-2 * max(1, |logit|_inf): bf16 keeps 8 significand bits and every one of the 20 conv
+        outputs is re-rounded (2^-9 relative each); sqrt(20) * 2^-9 ~ 0.9e-2 of the activation scale reaches the logits
+        for well-conditioned layers, the eval-mode BN gains (0.5 .. 1.5 / sqrt(var)) of the perturbed oracle model stretch
+        that to 1.5 .. 2.5e-2 on this input (measured max 1.9e-2): 3e-2 is the stated bound, the SURVEY's "~2e-2" sits inside;
+      * class-map agreement >= 99.9 % of the canvas cells."""
+    from deephisto_amd.examples.predict_full_patched import predict_full_patched
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    from deephisto_amd.patch_samplers.full_samplers import FullImageDenseSampler
+    h = w = 4096
+    P = S = 256
+    host = synth.synth_slide(h, w, 0)
+    oracle = oracle_net.seeded_model(77, 5, perturb_bn=True).eval()
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    want_logits, want_canvas, want_map = _oracle_pipeline(host, P, S, 64, 16, oracle)
+    model = get_model(5, "bf16")
+    model.load_state_dict(oracle.state_dict())
+    model.to(dev).eval()
+    smp = FullImageDenseSampler(host, layer=1, patch_size=P, batch_size=64, stride=S, device=dev)
+    cmap, logits = predict_full_patched(smp, model, 5, downscale=16, return_logits=True)
+    got = logits.cpu().numpy()
+    assert got.shape == want_logits.shape == (256, 5)
+    scale = max(1.0, float(np.abs(want_logits).max()))
+    err = float(np.abs(got - want_logits).max())
+    assert err <= 3e-2 * scale, f"bf16 logit error {err} at scale {scale}"
+    agree = float((cmap.cpu().numpy() == want_map).mean())
+    assert agree >= 0.999, f"class-map agreement {agree}"
+
+
+def test_full_size_fused_bf16_properties(dev):
+    """BASELINE configs[2] at full size (50 000^2, 38 416 tiles, bf16, fused gather + forward, micro-batch 1024 =
+    the large-launch code paths): size-independent properties instead of an oracle run --
+      * 64 tiles sampled from the whole-slide run (first / last of every grid section, the padded corner duplicates and
+        random ones) have logits bit-identical to a small launch of just those tiles (the small launches are the ones
+        checked against the CPU oracle, tests/test_gpu_resnet.py);
+      * the padded duplicates of the corner tile carry the corner's logits;
+      * the int64 class map equals the ORACLE's ordered accumulate + argmax (oracle/tiling.py) of the GPU's logits on the
+        whole 3125 x 3125 canvas, bit for bit."""
+    from deephisto_amd import tiles
+    from deephisto_amd.examples.predict_full_patched import predict_full_patched
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    from deephisto_amd.patch_samplers.full_samplers import FullImageDenseSampler
+    side, P = 50000, 256
+    slide = tiles.synth_slide(side, side, 0, dev)
+    oracle = oracle_net.seeded_model(31, 5, perturb_bn=True).eval()
+    model = get_model(5, "bf16")
+    model.load_state_dict(oracle.state_dict())
+    model.to(dev).eval()
+    smp = FullImageDenseSampler(slide, layer=1, patch_size=P, batch_size=64, stride=P, device=dev)
+    cmap, logits = predict_full_patched(smp, model, 5, downscale=16, micro_batch=1024, return_logits=True)
+    o = smp.origins
+    assert smp.n_tiles == 38416 and len(o) == 601 * 64 and tuple(logits.shape) == (601 * 64, 5)
+    rng = np.random.default_rng(0)
+    idx = np.unique(np.concatenate([[0, 194, 195, 38024, 38025, 38219, 38220, 38414, 38415, 38416, 38463],
+                                    rng.integers(0, 38416, 53)]))
+    small = model.forward_tiles(slide, torch.from_numpy(o[idx]).to(dev), P)
+    assert torch.equal(small, logits[torch.from_numpy(idx).to(dev)]), "whole-slide logits differ from a small launch of the same tiles"
+    assert torch.equal(logits[38416:], logits[38415:38416].expand(48, -1))          # corner padding duplicates
+    lg = logits.cpu().numpy()
+    assert np.isfinite(lg).all()
+    canvas = tiling.accumulate_logits(side, side, 5, 16, P, o, lg)
+    assert np.array_equal(cmap.cpu().numpy(), tiling.class_map(canvas))
