@@ -68,6 +68,11 @@ SIGNATURES = {
     "dh_train2_debug_act": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _p]),
     "dh_debug_conv_bn_act": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i32] * 9 + [_p]),
     "dh_debug_stem_out": (C.c_int, [_p, _i64, _i32, _p, _p]),
+    "dh_debug_wgrad_f32": (C.c_int, [_p, _p, _p] + [_i32] * 8 + [_p]),
+    "dh_debug_stem_wgrad_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
+    "dh_debug_dgrad_f32": (C.c_int, [_p, _p, _p, _p] + [_i32] * 7 + [_p]),
+    "dh_debug_bn_f32": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "dh_debug_maxpool_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_stamps": (C.c_int, [_i32, _p]),
     "dh_profile_start": (C.c_int, [_i32, _i32]),
     "dh_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),

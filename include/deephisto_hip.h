@@ -235,6 +235,25 @@ int dh_debug_conv_bn_act(const void* in_dev, const float* w_host, const float* s
                          int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t ks, int32_t stride,
                          int32_t relu, int32_t dtype, void* stream);
 int dh_debug_stem_out(dh_resnet18* net, int64_t n, int32_t patch, float* out_dev, void* stream);
+/* Backward building blocks of the float32 training engine, one at a time, exactly as dh_resnet18_backward launches them
+ * (all tensors float32 on the device, activations NHWC; each call allocates its own scratch and synchronises):
+ *   wgrad       dW[cout][cin][ks][ks] from x [B][Hi][Wi][cin] and dz [B][Ho][Wo][cout]; mode 1 forces the per-tap kernel
+ *   stem_wgrad  dW[64][3][7][7] from the NCHW image and dz [B][P/2][P/2][64]
+ *   dgrad       dX from dz and the weights [cout][cin][ks][ks] (+ res): stride 2 = zero-upsampled gradient (3x3) /
+ *               low-resolution product scattered back (1x1)
+ *   bn          training-mode BN forward (+ res, ReLU) and, when dy is given, backward (dz, masked gradient g, dgamma, dbeta);
+ *               stats_out = [mean | invstd | running_mean | running_var] after one update from (0, 1)
+ *   maxpool     3x3/2 forward and (dy given) backward through the recorded first-maximum positions */
+int dh_debug_wgrad_f32(const float* dz_dev, const float* x_dev, float* dw_dev, int32_t B, int32_t Hi, int32_t Wi,
+                       int32_t cin, int32_t cout, int32_t ks, int32_t stride, int32_t mode, void* stream);
+int dh_debug_stem_wgrad_f32(const float* dz_dev, const float* x_nchw_dev, float* dw_dev, int32_t B, int32_t P, void* stream);
+int dh_debug_dgrad_f32(const float* dz_dev, const float* w_dev, const float* res_dev, float* dx_dev, int32_t B, int32_t Hi,
+                       int32_t Wi, int32_t cin, int32_t cout, int32_t ks, int32_t stride, void* stream);
+int dh_debug_bn_f32(const float* z_dev, const float* gamma_dev, const float* beta_dev, const float* res_dev, int32_t relu,
+                    float* y_dev, const float* dy_dev, float* dz_dev, float* g_dev, float* dgamma_dev, float* dbeta_dev,
+                    float* stats_out_dev, int64_t rows, int32_t C, void* stream);
+int dh_debug_maxpool_f32(const float* x_dev, float* y_dev, const float* dy_dev, float* dx_dev, int32_t B, int32_t Hi, int32_t Wi,
+                         int32_t C, void* stream);
 /* dh_debug_stamps: switch the 3x3-conv kernel to its cycle-stamped diagnostic variant and/or read
  * (and clear) its 8x8 table of summed phase cycles; out64_host may be NULL. */
 int dh_debug_stamps(int32_t enable, unsigned long long* out64_host);

@@ -148,10 +148,9 @@ def test_ondisk_mode_streams_and_matches_resident(dev, tmp_path):
 def test_bf16_pipeline_class_map_gate(dev):
     """SURVEY section 8d gate for the bf16 whole pipeline: predict_full_patched in bf16 on a 4096^2 closed-form slide
     (256 tiles, BASELINE configs[0] geometry) against the float32 ORACLE pipeline on the CPU:
-      * per-tile logits within 3e-2 * max(1, |logit|_inf): bf16 keeps 8 significand bits and every one of the 20 conv
-        outputs is re-rounded (2^-9 relative each); sqrt(20) * 2^-9 ~ 0.9e-2 of the activation scale reaches the logits
-        for well-conditioned layers, the eval-mode BN gains (0.5 .. 1.5 / sqrt(var)) of the perturbed oracle model stretch
-        that to 1.5 .. 2.5e-2 on this input (measured max 1.9e-2): 3e-2 is the stated bound, the SURVEY's "~2e-2" sits inside;
+      * per-tile logits within 2e-2 * max(1, |logit|_inf) -- the SURVEY's stated bf16 tolerance: bf16 keeps 8 significand
+        bits and every one of the 20 conv outputs is re-rounded (2^-9 relative each), sqrt(20) * 2^-9 ~ 0.9e-2 of the
+        activation scale reaches the logits (measured on this input: 1.19e-2 absolute at |logit|_inf = 1.66, i.e. 0.72e-2);
       * class-map agreement >= 99.9 % of the canvas cells."""
     from deephisto_amd.examples.predict_full_patched import predict_full_patched
     from deephisto_amd.models.patch_cls_simple.model import get_model
@@ -171,8 +170,8 @@ def test_bf16_pipeline_class_map_gate(dev):
     assert got.shape == want_logits.shape == (256, 5)
     scale = max(1.0, float(np.abs(want_logits).max()))
     err = float(np.abs(got - want_logits).max())
-    assert err <= 3e-2 * scale, f"bf16 logit error {err} at scale {scale}"
-    agree = float((cmap.cpu().numpy() == want_map).mean())
+    assert err <= 2e-2 * scale, f"bf16 logit error {err} at scale {scale}"
+    agree = float((cmap.cpu().numpy() == want_map).mean())       # measured: 1.0
     assert agree >= 0.999, f"class-map agreement {agree}"
 
 
