@@ -147,7 +147,7 @@ def test_maxpool_forward_backward_kernels(dev, B, H, C):
     from deephisto_amd._lib import check, lib
     g = torch.Generator().manual_seed(H)
     x = torch.randn(B, C, H, H, generator=g)
-    x[:, :, ::3, ::5] = x[:, :, 1::3, ::5][:, :, :x[:, :, ::3, ::5].shape[2]] if H % 3 == 1 else x[:, :, ::3, ::5]   # a few exact ties
+    x[:, ::2] = (x[:, ::2] * 2).round() / 2     # half of the channels quantised: plenty of exact ties inside the 3x3 windows
     x = x.double().requires_grad_(True)
     y = F.max_pool2d(x, 3, 2, 1)
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
