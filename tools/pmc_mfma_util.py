@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """MFMA utilisation per layer from one rocprofv3 --pmc pass (SQ_BUSY_CU_CYCLES, SQ_VALU_MFMA_BUSY_CYCLES, SQ_LDS_IDX_ACTIVE,
 SQ_LDS_BANK_CONFLICT) of tools/fwd_once.py.  Tooling only.  usage: pmc_mfma_util.py <dir> <out.json>
-util = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES per dispatch (both summed over the chip by rocprofv3), averaged per layer class;
+util = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES) per dispatch: both counters are in shader cycles summed over the chip,
+the MFMA counter over the 4 SIMDs (= 4 matrix pipes) of every CU, the CU counter once per CU (cross-check: a 77.3 GFLOP launch is
+2.36 M v_mfma_f32_32x32x16_bf16 x 32 cycles = 75.5 M pipe-cycles against 256 CUs x 67 us x 1.9 GHz = 32.6 M CU-cycles -> ratio 2.3 = 4 x 0.58;
+the in-kernel phase stamps give the same share); averaged per layer class;
 layers are labelled by launch order inside a forward (trace_summary.SEQ)."""
 import collections
 import csv
@@ -33,7 +36,7 @@ for d in sorted(by_disp):
             agg[lab][k].append(v)
 doc = {"command": "rocprofv3 --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -- "
                   "python3 tools/fwd_once.py 256 3   (bf16 forwards of 256 tiles of 256x256)",
-       "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES; lds_active = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES "
+       "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES); lds_active = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES "
                      "(ROCm 7.2 ships no gfx950 derived-metric section; raw counters, averaged over the launches of a layer class)",
        "layers": {}}
 for lab in ["stem+pool"] + sorted(set(SEQ), key=SEQ.index):
@@ -42,7 +45,7 @@ for lab in ["stem+pool"] + sorted(set(SEQ), key=SEQ.index):
     a = {k: sum(v) / len(v) for k, v in agg[lab].items()}
     busy = a.get("SQ_BUSY_CU_CYCLES", 0.0)
     doc["layers"][lab] = {"launches": len(agg[lab]["SQ_BUSY_CU_CYCLES"]), **{k: round(v) for k, v in a.items()},
-                          "mfma_util": round(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / busy, 4) if busy else None,
+                          "mfma_util": round(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * busy), 4) if busy else None,
                           "lds_active": round(a.get("SQ_LDS_IDX_ACTIVE", 0.0) / busy, 4) if busy else None}
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps(doc["layers"], indent=1))
