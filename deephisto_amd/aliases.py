@@ -6,7 +6,7 @@ The reference's callers import the hot path as
     examples.predict_full_patched
     anno.utils
     utils                                  (top-level: get_img_ano_paths)
-(`/root/reference/examples/predict_full_patched.py:12-19`, `models/patch_cls_simple/train.py:20-26`).
+(`examples/predict_full_patched.py:12-19`, `models/patch_cls_simple/train.py:20-26` of the reference).
 `install_aliases()` registers this package's modules under those names in `sys.modules`, so such a
 caller runs unchanged inside a process that has called it; the `compat/` directory at the repository
 root gives the same names to a fresh interpreter (`PYTHONPATH=compat python -m models.patch_cls_simple.train`).
