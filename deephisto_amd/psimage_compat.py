@@ -57,6 +57,17 @@ class ArraySlide:
     def get_region_from_layer(self, layer, p0, p1):
         return self._a[p0[0]:p1[0], p0[1]:p1[1], :]
 
+    def get_region(self, p0, p1, target_hw=None):
+        """`PSImage.get_region(p0, p1, target_hw)` as examples/predict_full_patched.py:104 calls it: the region resampled to
+        `target_hw`.  psimage's own resampler is third-party and unknown here: nearest source pixel (`floor(i * h / th)`)."""
+        reg = self._a[p0[0]:p1[0], p0[1]:p1[1], :]
+        if target_hw is None:
+            return np.ascontiguousarray(reg)
+        th, tw = target_hw
+        ys = (np.arange(th) * reg.shape[0]) // th
+        xs = (np.arange(tw) * reg.shape[1]) // tw
+        return np.ascontiguousarray(reg[ys][:, xs])
+
 
 def open_slide(source):
     """Return a PSImage-like reader for a path, an ndarray or a reader object."""
