@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <map>
 #include <mutex>
 #include <set>
@@ -675,7 +676,7 @@ int zero_page(const void** out) {
 // decode, a few KiB each.  The key holds the batch only through the tile count; the cache is bounded (a caller that
 // sweeps batch sizes would otherwise grow it without end): past CONV3_TABLE_CAP entries of a device it is emptied
 // (hipFree waits for kernels that still read a table).
-struct Conv3Tables { int* lane = nullptr; int4* tile = nullptr; };
+struct Conv3Tables { int* lane = nullptr; int4* tile = nullptr; unsigned* mask = nullptr; };
 std::map<std::vector<int>, Conv3Tables> g_conv3_tables;
 constexpr size_t CONV3_TABLE_CAP = 256;
 
@@ -683,16 +684,20 @@ template <int STRIDE, int NT, int WAVES, int ESZ, int MT>
 int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out) {
   constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
   const std::vector<int> key = {current_device(), STRIDE, NT, WAVES, MT, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi,
-                                p.Cin, p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes};
+                                p.Cin, p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes, p.Ho, p.Wo, p.Cout, p.out_px,
+                                p.out_cb};
   std::lock_guard<std::mutex> lk(g_host_mu);
   auto it = g_conv3_tables.find(key);
   if (it != g_conv3_tables.end()) { *out = it->second; return DH_OK; }
   if (g_conv3_tables.size() >= CONV3_TABLE_CAP) {
-    for (auto& kv : g_conv3_tables) { (void)hipFree(kv.second.lane); (void)hipFree(kv.second.tile); }
+    for (auto& kv : g_conv3_tables) { (void)hipFree(kv.second.lane); (void)hipFree(kv.second.tile); (void)hipFree(kv.second.mask); }
     g_conv3_tables.clear();
   }
-  const int threads = WAVES * 64, stride = 2 * NT + 2 * MAXJ;
+  const int threads = WAVES * 64, stride = 2 * NT + MAXJ;
   std::vector<int> lane((size_t)threads * stride);
+  // per-thread geometry kept on the host for the mask rows below: output pixel (ty, tx, img) per n-tile, window piece (hy, hx, img, live)
+  std::vector<std::array<int, 3>> pix((size_t)threads * NT);
+  std::vector<std::array<int, 4>> win((size_t)threads * MAXJ);
   for (int tid = 0; tid < threads; ++tid) {
     const int l = tid & 63, wave = tid >> 6;
     int* row = &lane[(size_t)tid * stride];
@@ -712,8 +717,9 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
       const int pidx = ((MT == 2 ? wave : wave >> 1) * NT + nt) * 32 + lane_pos(l & 31);   // MT == 1: wave pairs share pixels
       const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
       const int ty = rem / p.TW, tx = rem % p.TW;
-      row[2 * nt] = ty | (tx << 8) | (img << 16);
-      row[2 * nt + 1] = (img * p.HR + ty * STRIDE) * p.HP + tx;
+      pix[(size_t)tid * NT + nt] = {ty, tx, img};
+      row[nt] = img * p.Ho * p.Wo * p.Cout + (ty * p.Wo + tx) * p.out_px;   // output element offset relative to the tile's origin
+      row[NT + nt] = (img * p.HR + ty * STRIDE) * p.HP + tx;
     }
     // window DMA: instruction i = wave + WAVES*j fills LDS pixels 16i..16i+15; lane l fills LDS slot (l&3)
     // of pixel 16i + l/4 with GLOBAL slot (l&3) ^ swizzle(pixel)
@@ -726,10 +732,36 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
       if (STRIDE == 2) hx = 2 * (c % p.HPH) + c / p.HPH;
       const bool live = i < p.n_win_instr && img < p.IMGS && hx < p.HC;
       const int g = (l & 3) ^ ((px >> 2) & 3);
-      row[2 * NT + 2 * j] = img * p.Hi * p.Wi * p.Cin * ESZ + ((hy - 1) * p.Wi + hx - 1) * p.in_px_bytes + g * 16;
-      row[2 * NT + 2 * j + 1] = (hy & 0xFF) | ((hx & 0xFF) << 8) | ((img & 0xFF) << 16) | ((live ? 1 : 0) << 24);
+      row[2 * NT + j] = img * p.Hi * p.Wi * p.Cin * ESZ + ((hy - 1) * p.Wi + hx - 1) * p.in_px_bytes + g * 16;
+      win[(size_t)tid * MAXJ + j] = {hy, hx, img, live ? 1 : 0};
     }
   }
+  // Mask rows: one per distinct (oy0, ox0, images left in the group): bit j = window piece j of the thread lies inside the
+  // image, bit 16 + nt = output pixel nt exists.  The kernel fetches its word of the row one tile ahead.
+  std::map<std::array<int, 3>, int> mask_row;
+  std::vector<unsigned> mask;
+  auto mask_row_of = [&](int img0, int oy0, int ox0) {
+    const std::array<int, 3> mk = {oy0, ox0, std::min(p.IMGS, std::max(0, p.B - img0))};
+    auto it = mask_row.find(mk);
+    if (it != mask_row.end()) return it->second;
+    const int r = (int)mask_row.size();
+    mask_row[mk] = r;
+    mask.resize((size_t)(r + 1) * threads);
+    for (int tid = 0; tid < threads; ++tid) {
+      unsigned m = 0;
+      for (int j = 0; j < MAXJ; ++j) {
+        const auto& w = win[(size_t)tid * MAXJ + j];
+        const int iy = oy0 * STRIDE + w[0] - 1, ix = ox0 * STRIDE + w[1] - 1;
+        if (w[3] && w[2] < mk[2] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) m |= 1u << j;
+      }
+      for (int nt = 0; nt < NT; ++nt) {
+        const auto& q = pix[(size_t)tid * NT + nt];
+        if (q[2] < mk[2] && oy0 + q[0] < p.Ho && ox0 + q[1] < p.Wo) m |= 1u << (16 + nt);
+      }
+      mask[(size_t)r * threads + tid] = m;
+    }
+    return r;
+  };
   // Schedule [iters][grid]: which (pixel tile, cout block) a workgroup takes in which iteration.  Workgroups are
   // dispatched round-robin over the 8 XCDs (workgroup w -> XCD w % 8), each with its own 4 MiB L2.  The ncb cout
   // blocks of a pixel tile go to ncb workgroups of ONE XCD in the same iteration (`xcd_group`), so the staged window
@@ -753,14 +785,21 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
         cb = T_ % ncb; pt = T_ / ncb;
       }
       const int valid = pt < n_pt ? 1 : 0, t = pt % tiles_per_img;
-      tile[(size_t)it * grid + w] = make_int4(cb | (valid << 16), (pt / tiles_per_img) * p.IMGS, (t / p.tiles_x) * p.TH,
-                                              (t % p.tiles_x) * p.TW);
+      const int img0 = valid ? (pt / tiles_per_img) * p.IMGS : 0, oy0 = (t / p.tiles_x) * p.TH, ox0 = (t % p.tiles_x) * p.TW;
+      const int mrow = mask_row_of(img0, oy0, ox0);
+      DH_REQUIRE(mrow < 4096, "conv3x3: too many distinct tile positions for the mask table");
+      const int64_t win_off = (int64_t)img0 * p.Hi * p.Wi * p.Cin * ESZ + (int64_t)((oy0 * STRIDE) * p.Wi + ox0 * STRIDE) * p.in_px_bytes;
+      const int64_t out_off = (int64_t)img0 * p.Ho * p.Wo * p.Cout + (int64_t)(oy0 * p.Wo + ox0) * p.out_px + (int64_t)cb * p.out_cb;
+      DH_REQUIRE(win_off < ((int64_t)1 << 32) && out_off < ((int64_t)1 << 32), "conv3x3: tensor larger than 4 Gi elements / bytes");
+      tile[(size_t)it * grid + w] = make_int4(cb | (valid << 16) | (mrow << 20), (int)(uint32_t)win_off, (int)(uint32_t)out_off, 0);
     }
   Conv3Tables tb;
   DH_HIP(hipMalloc((void**)&tb.lane, lane.size() * sizeof(int)));
   DH_HIP(hipMalloc((void**)&tb.tile, tile.size() * sizeof(int4)));
+  DH_HIP(hipMalloc((void**)&tb.mask, mask.size() * sizeof(unsigned)));
   DH_HIP(hipMemcpy(tb.lane, lane.data(), lane.size() * sizeof(int), hipMemcpyHostToDevice));
   DH_HIP(hipMemcpy(tb.tile, tile.data(), tile.size() * sizeof(int4), hipMemcpyHostToDevice));
+  DH_HIP(hipMemcpy(tb.mask, mask.data(), mask.size() * sizeof(unsigned), hipMemcpyHostToDevice));
   g_conv3_tables[key] = tb;
   *out = tb;
   (void)groups_img;
@@ -789,7 +828,7 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   Conv3Tables tb;
   int rc = conv3_tables<STRIDE, NT, WAVES, (int)sizeof(T), MT>(p, L.cout / 64, groups, &tb);
   if (rc) return rc;
-  p.lane_tab = tb.lane; p.tile_tab = tb.tile;
+  p.lane_tab = tb.lane; p.tile_tab = tb.tile; p.mask_tab = tb.mask;
   if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES>), 160 * 1024)) ||
       (rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>), 160 * 1024))) return rc;
   if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
