@@ -1,0 +1,78 @@
+"""First execution of the RCCL (backend "nccl") code paths on real hardware.
+
+The builder's box has ONE GPU and RCCL refuses two ranks on one device, so the collectives of N > 1 cannot run here; what CAN
+run is every RCCL call this package makes, on a one-rank process group, on the very tensors it makes them on: the flat
+all-gather of per-tile logits (`exchange_logits`), and the bucketed asynchronous all-reduce of slices of the native library's
+gradient arena (memory hipMalloc'ed OUTSIDE torch's allocator, viewed through __cuda_array_interface__, launched from a side
+stream behind an event, waited for on the compute stream).  With one rank a sum is the identity, so the results are checked
+exactly; the multi-rank arithmetic is covered on gloo (tests/test_ddp.py, tests/test_distributed_gloo.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from deephisto_amd.examples.predict_full_patched import exchange_logits
+    from deephisto_amd.models.patch_cls_simple.ddp import BucketReducer, allreduce_mean_
+    from deephisto_amd.models.patch_cls_simple.model import ce_loss, get_model
+    from deephisto_amd._lib import check, lib
+    out = {}
+    # 1. the predict exchange
+    local = torch.randn(4802, 5, device=dev)
+    full = exchange_logits(local, 4802)
+    out["gather"] = bool(torch.equal(full, local))
+    # 2. bucketed all-reduce of the native gradient arena (bf16 engine) inside train_step's machinery
+    torch.manual_seed(0)
+    m = get_model(5, arch="resnet50").to(dev).train()
+    x = torch.rand(4, 3, 64, 64, device=dev)
+    y = torch.randint(0, 5, (4,), device=dev)
+    eng = m._engine
+    logits = eng.forward(x, True, pull_stats=False)
+    _, dl = ce_loss(logits, y, want_grad=True)
+    check(lib().dh_train2_backward(eng.handle, dl.data_ptr(), None), "backward")
+    want = m.flat_gradients(dev).clone()
+    red = eng._arm_overlap(dev, None, 25 * 1024 * 1024)
+    check(lib().dh_train2_backward(eng.handle, dl.data_ptr(), None), "backward")      # callbacks fire -> async all_reduce per bucket
+    eng._finish_overlap(red)
+    torch.cuda.synchronize()
+    out["buckets"] = [b for b, _, _ in eng.overlap_log]
+    out["arena"] = bool(torch.equal(m.flat_gradients(dev), want))                     # world 1: sum / 1 = identity
+    # 3. the un-bucketed helper and the f32 engine's arena
+    m18 = get_model(5, "f32").to(dev).train()
+    m18.train_step(x, y, lr=1e-4)
+    g18 = m18.flat_gradients(dev)
+    before = g18.clone()
+    allreduce_mean_(g18)
+    torch.cuda.synchronize()
+    out["arena18"] = bool(torch.equal(g18, before))
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_calls_on_one_rank(built_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert out["gather"] and out["arena"] and out["arena18"], out
+    assert out["buckets"] == [0, 1, 2, 3]
