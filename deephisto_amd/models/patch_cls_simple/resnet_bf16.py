@@ -232,8 +232,8 @@ class ResNet50HIP(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3]:
             raise ValueError(f"expected [n, 3, P, P], got {tuple(x.shape)}")
         x = x.detach().to(torch.float32).contiguous()
-        self._engine.pull_parameters() if self._engine.native_ahead else None
         if self.training and torch.is_grad_enabled():
+            self._engine.pull_parameters()   # a torch optimizer will step the nn.Parameters: they must hold the newest values
             return _TrainForward2.apply(x, self._engine, *self.parameters())
         return self._engine.forward(x, self.training)
 

@@ -29,6 +29,14 @@ from .model import ce_loss, get_model
 from ...patch_samplers.region_samplers import AnnoRegionRndSampler, RectRegionRndSampler, synthetic_regions
 
 
+def _rank_world():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def _synthetic_sampler(cfg, device):
     from ... import tiles
 
@@ -36,7 +44,8 @@ def _synthetic_sampler(cfg, device):
     slide = tiles.synth_slide(side, side, 0, device)
     regions = synthetic_regions(side, side, cfg["model"]["n_classes"], seed=0)
     return RectRegionRndSampler(slide, regions, layer=cfg["dataset"]["layer"], patch_size=cfg["dataset"]["patch_size"],
-                                patches_from_one_region=cfg["dataset"]["patches_from_one_region"], device=device)
+                                patches_from_one_region=cfg["dataset"]["patches_from_one_region"], seed=_rank_world()[0],
+                                device=device)   # data parallel: every rank draws its own stream of patches
 
 
 class _PlateauLR:
@@ -77,7 +86,11 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
             sampler = _synthetic_sampler(cfg, device)
 
     bs = cfg["training"]["batch_size"]
-    model = get_model(cfg["model"]["n_classes"], cfg.get("runtime", {}).get("compute_dtype", "f32")).to(device)
+    # `model.arch: resnet50` selects the backbone of BASELINE configs[4] (bf16 engine); under torchrun (one process per GPU)
+    # train_step averages the gradients over the ranks (bucketed all-reduce overlapped with backward) and rank 0 writes the files
+    rank, world = _rank_world()
+    model = get_model(cfg["model"]["n_classes"], cfg.get("runtime", {}).get("compute_dtype", "f32"),
+                      arch=cfg["model"].get("arch", "resnet18")).to(device)
     sched = _PlateauLR(cfg["training"]["lr"])
     history = {"train_loss": [], "train_acc": [], "val_loss": [], "val_acc": [], "lr": []}
     best_val_acc = 0.0
@@ -112,7 +125,8 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
         log(f"Current Learning Rate: {lr:.6f}")
         if val_acc > best_val_acc:
             best_val_acc = val_acc
-            torch.save(model.state_dict(), out_dir / "best_model.pth")
+            if rank == 0:
+                torch.save(model.state_dict(), out_dir / "best_model.pth")
         for k, v in zip(history, (train_loss, train_acc, val_loss, val_acc, lr)):
             history[k].append(v)
     return model, history

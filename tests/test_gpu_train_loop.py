@@ -237,3 +237,35 @@ def test_reference_caller_shape_through_aliases(dev, tmp_path):
         assert get_model(5).__class__.__name__ == model.__class__.__name__
     finally:
         deephisto_amd.uninstall_aliases()
+
+
+def test_train_mirror_resnet50_bf16(dev, tmp_path):
+    """The same entry point with `model.arch: resnet50` (BASELINE configs[4]: bf16 engine): learns the separable synthetic
+    classes, the checkpoint has torchvision's ResNet-50 layout and evaluates like the oracle holding it (bf16 tolerance)."""
+    from deephisto_amd.models.patch_cls_simple.train import train
+    from deephisto_amd.patch_samplers.region_samplers import RectRegion, RectRegionRndSampler
+    from oracle import resnet50 as o50
+    side = 1024
+    host = synth.synth_slide(side, side, 1) // 4
+    regions = []
+    for i, name in enumerate(["AT", "BG", "LP", "MM", "TUM"]):
+        y0 = i * 200
+        host[y0:y0 + 200, :, :] += np.array([40 * i, 200 - 40 * i, 20 * i], dtype=np.uint8)
+        regions.append(RectRegion(name, y0, 0, y0 + 200, side))
+    smp = RectRegionRndSampler(host, regions, layer=1, patch_size=64, seed=0, device=dev)
+    cfg = {"model": {"n_classes": 5, "arch": "resnet50"},
+           "training": {"batch_size": 16, "n_epochs": 2, "lr": 1e-3, "save_dir": str(tmp_path / "ck"),
+                        "out_dir": str(tmp_path / "out"), "val_steps": 2},
+           "dataset": {"folder": "/nonexistent", "layer": 1, "patch_size": 64, "patches_from_one_region": 4}}
+    torch.manual_seed(0)
+    model, hist = train(cfg, sampler=smp, epochs=2, steps_per_epoch=40, log=lambda *a: None)
+    assert hist["train_loss"][1] < hist["train_loss"][0] and hist["train_acc"][1] > 0.3
+    ck = torch.load(tmp_path / "out" / "best_model.pth", weights_only=True)
+    ref = o50.ResNet50Oracle(5)
+    ref.load_state_dict(ck)
+    x = torch.rand(4, 3, 64, 64)
+    with torch.no_grad():
+        want = ref.eval()(x)
+    model.load_state_dict(ck)
+    got = model.eval()(x.to(dev)).cpu()
+    assert float((got - want).abs().max()) <= 5e-2 * max(1.0, float(want.abs().max()))
