@@ -218,3 +218,33 @@ def test_bucket_layout_and_callback_order(dev):
     # fc sits in the first bucket, the stem in the last: completion order of the backward pass
     sd_first = {k for k, _ in m.named_parameters()}
     assert "fc.weight" in sd_first
+
+
+@pytest.mark.parametrize("arch,B,P", [("resnet50", 2, 256), ("resnet50", 3, 128), ("resnet18", 5, 224), ("resnet50", 1, 160)])
+def test_shape_sweep_forward_backward(dev, arch, B, P):
+    """Other patch sizes / batch sizes (odd maps: 160 -> 5x5, 224 -> 7x7; 256 -> the 64-pixel-wide wgrad rows; batch 1): forward
+    against the bf16-emulating oracle, gradients finite and -- for the last layers, whose gradient does not pass through deep
+    ReLU patterns -- close to the emulation's."""
+    ref, m = _pair(dev, arch, 17, 0.2 if arch == "resnet50" else 1.0)
+    g = torch.Generator().manual_seed(B + P)
+    x = torch.rand(B, 3, P, P, generator=g)
+    y = torch.randint(0, 5, (B,), generator=g)
+    if B == 1:
+        ref.eval(); m.eval()     # one sample per channel at the deepest maps has no batch statistics worth comparing
+        with torch.no_grad():
+            want = forward_bf16(ref, x)
+            got = m(x.to(dev)).cpu()
+        assert float((got - want).abs().max()) <= 3e-2 * max(1.0, float(want.abs().max()))
+        return
+    emu = copy.deepcopy(ref)
+    out_emu = forward_bf16(emu, x)
+    F.cross_entropy(out_emu, y).backward()
+    out = m(x.to(dev))
+    F.cross_entropy(out, y.to(dev)).backward()
+    assert float((out.detach().cpu() - out_emu.detach()).abs().max()) <= 5e-2 * max(1.0, float(out_emu.detach().abs().max()))
+    want = dict(emu.named_parameters())
+    for k, p in m.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    for k in ("fc.weight", "fc.bias"):
+        e = float((dict(m.named_parameters())[k].grad.cpu() - want[k].grad).norm() / (want[k].grad.norm() + 1e-30))
+        assert e <= 0.15, (k, e)
