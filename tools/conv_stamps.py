@@ -33,4 +33,5 @@ for r, n in enumerate(names):
         continue
     tot = v[:6].sum()
     ghz = tot / max(v[7], 1) * 0.1   # shader cycles per 100 MHz tick
-    print(f"{n:12s} {int(v[6]):5d} {tot / v[6]:8.0f}  " + "  ".join(f"{100 * a / tot:5.1f}" for a in v[:6]) + f"   clock {ghz:4.2f} GHz")
+    clock = f"   clock {ghz:4.2f} GHz" if r < 7 else ""    # the stem kernel records no real-time counter
+    print(f"{n:12s} {int(v[6]):5d} {tot / v[6]:8.0f}  " + "  ".join(f"{100 * a / tot:5.1f}" for a in v[:6]) + clock)
