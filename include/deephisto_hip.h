@@ -224,6 +224,15 @@ int dh_train2_adam_step(dh_train2* net, float lr, float beta1, float beta2, floa
 /* test hook: float32 copy of conv `conv_name`'s raw output (what = 0) or BN/ReLU output (what = 1) of the last forward */
 int dh_train2_debug_act(dh_train2* net, const char* conv_name, int32_t what, float* out_dev, int64_t n_elem, void* stream);
 
+/* test hooks of the engine's GEMM-shaped kernels on caller data (bf16 bits as uint16; synchronise; `repeat` launches for timing):
+ * gemm1x1: out[M][N] = A[rows][K] . W[N][K]^T (+ res), stride 2 = row gather (b, 2 oy, 2 ox) from [B][Hi][Wi][K];
+ * wgrad:   float32 dW[cout][cin][ks][ks] from x [B][Hi][Wi][cin] and dz [B][Ho][Wo][cout] (ks 1 or 3). */
+int dh_debug_gemm1x1_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const uint16_t* res_dev, uint16_t* out_dev, int64_t M,
+                          int32_t N, int32_t K, int32_t stride, int32_t Ho, int32_t Wo, int32_t Hi, int32_t Wi, int32_t repeat,
+                          void* stream);
+int dh_debug_wgrad_bf16(const uint16_t* dz_dev, const uint16_t* x_dev, float* dw_dev, int32_t B, int32_t Hi, int32_t Wi,
+                        int32_t cin, int32_t cout, int32_t ks, int32_t stride, int32_t repeat, void* stream);
+
 /* ---- debug / test hooks (not part of the drop-in boundary) ---------------------
  * dh_debug_conv_bn_act: one conv (ks in {1,3}, pad ks/2) + per-channel scale/shift
  * (+ residual) (+ ReLU) on NHWC data of `dtype`; weights are float32
