@@ -159,3 +159,59 @@ def test_maxpool_forward_backward_kernels(dev, B, H, C):
     check(lib().dh_debug_maxpool_f32(xd.data_ptr(), yd.data_ptr(), dyd.data_ptr(), dxd.data_ptr(), B, H, H, C, None), "maxpool")
     assert torch.equal(_nchw(yd), y.detach().float())
     assert _rel(_nchw(dxd), want) <= 1e-6      # gradients are routed, not computed: only float32 sums of <= 4 terms
+
+
+# ---- bf16 engine (train2): the GEMM-shaped kernels on their own ------------------------------------------------------
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("M,N,K,stride", [(1000, 64, 64, 1), (3136, 256, 64, 1), (777, 128, 512, 1), (3136, 2048, 512, 1),
+                                          (4 * 14 * 14, 512, 256, 2), (2 * 28 * 28, 128, 64, 2)])
+def test_gemm1x1_bf16_kernel(dev, M, N, K, stride):
+    """out = A . W^T (+ res) on bf16 MFMA with f32 accumulation against float64 on the same bf16 operands: the products are exact,
+    only the output rounding to bf16 (2^-9 relative) and the f32 summation order remain."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(M + N + K)
+    w = _bf(torch.randn(N, K, generator=g) * (1.0 / K) ** 0.5)
+    res = _bf(torch.randn(M, N, generator=g))
+    if stride == 1:
+        a = _bf(torch.randn(M, K, generator=g))
+        rows, geo = a, (1, 1, 1, 1)
+    else:
+        B, Ho = (4, 14) if K == 256 else (2, 28)
+        full = _bf(torch.randn(B, 2 * Ho, 2 * Ho, K, generator=g))
+        a, rows, geo = full, full[:, ::2, ::2, :].reshape(M, K), (Ho, Ho, 2 * Ho, 2 * Ho)
+    want = rows.double() @ w.double().T + res.double()
+    ad, wd, rd = a.to(dev).bfloat16().contiguous(), w.to(dev).bfloat16().contiguous(), res.to(dev).bfloat16().contiguous()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    check(lib().dh_debug_gemm1x1_bf16(ad.data_ptr(), wd.data_ptr(), rd.data_ptr(), out.data_ptr(), M, N, K, stride, *geo, 1, None), "gemm")
+    got = out.float().cpu().double()
+    assert float((got - want).abs().max()) <= 2 ** -8 * max(1.0, float(want.abs().max()))
+    assert _rel(got, want) <= 3e-3
+
+
+@pytest.mark.parametrize("ks,stride,cin,cout,B,H", [
+    (3, 1, 64, 64, 3, 56), (3, 1, 256, 256, 4, 14), (3, 2, 128, 128, 3, 28), (3, 1, 512, 512, 5, 7), (3, 1, 128, 128, 2, 12),
+    (1, 1, 64, 256, 3, 56), (1, 1, 256, 64, 2, 28),          # 64 x 64 tiles (64-channel layers)
+    (1, 1, 512, 128, 3, 28), (1, 1, 256, 1024, 4, 14), (1, 1, 2048, 512, 5, 7), (1, 2, 256, 512, 3, 28), (1, 1, 1024, 256, 2, 6),   # 128 x 128 tiles
+])
+def test_wgrad_bf16_kernels(dev, ks, stride, cin, cout, B, H):
+    """dW through the transposed-LDS-read kernels (3x3 tap groups, 1x1 with 64 x 64 and 128 x 128 workgroup tiles; odd maps, stride 2,
+    row pitches that are not multiples of 4) against torch autograd in float64 on the same bf16 operands: relative L2 <= 1e-5
+    (exact products, f32 accumulation)."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(ks * 1000 + cin + cout + H)
+    x = _bf(torch.randn(B, cin, H, H, generator=g)).double()
+    w = torch.zeros(cout, cin, ks, ks, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, None, stride, ks // 2)
+    dz = _bf(torch.randn(y.shape, generator=g)).double()
+    (want,) = torch.autograd.grad(y, w, dz)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()
+    dzd = dz.float().permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()
+    dw = torch.empty(cout, cin, ks, ks, dtype=torch.float32, device=dev)
+    check(lib().dh_debug_wgrad_bf16(dzd.data_ptr(), xd.data_ptr(), dw.data_ptr(), B, H, H, cin, cout, ks, stride, 1, None), "wgrad bf16")
+    assert _rel(dw.cpu(), want) <= TOL
+    if ks == 3:
+        for t in ((0, 0), (0, 2), (2, 0), (2, 2), (1, 1)):
+            assert _rel(dw.cpu()[:, :, t[0], t[1]], want[:, :, t[0], t[1]]) <= TOL, t
