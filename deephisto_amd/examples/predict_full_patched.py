@@ -161,7 +161,7 @@ def exchange_logits(local: torch.Tensor, n_unique: int, group=None) -> torch.Ten
 
 def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_classes: int,
                          downscale: int = 16, micro_batch: int | None = None, group=None,
-                         return_logits: bool = False, streams: int = 2):
+                         return_logits: bool = False, streams: int = 2, dedupe_padding: bool = False):
     """Device-resident whole-slide prediction (rows a1-a8 end to end).
 
     Single process: every tile (padding duplicates included) goes through the fused
@@ -172,6 +172,8 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     (n_unique x n_cls floats in total), and every rank finishes the map; the corner
     tile's padding duplicates are reconstructed from the gathered logits so the
     canvas equals the single-GPU / reference result.
+    `dedupe_padding=True` leaves the padding duplicates of the corner tile out of the accumulation (the reference adds them,
+    predict_full_patched.py:49-54, which is the default here).
     Returns int64[h//d, w//d] on the device (and the float32[n_padded, n_cls] logits).
     """
     import torch.distributed as dist
@@ -214,7 +216,10 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     logits_unique = exchange_logits(local, n_unique, group) if distributed else local[:n_unique]
     pad = n_padded - n_unique
     logits = torch.cat([logits_unique, logits_unique[-1:].expand(pad, -1)]) if pad else logits_unique
-    _, cmap = tiles.accumulate_logits(logits.contiguous(), origins, P, downscale, sampler.h, sampler.w)
+    if dedupe_padding:
+        _, cmap = tiles.accumulate_logits(logits_unique.contiguous(), origins[:n_unique], P, downscale, sampler.h, sampler.w)
+    else:
+        _, cmap = tiles.accumulate_logits(logits.contiguous(), origins, P, downscale, sampler.h, sampler.w)
     return (cmap, logits) if return_logits else cmap
 
 

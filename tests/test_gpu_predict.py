@@ -143,6 +143,52 @@ def test_ondisk_mode_streams_and_matches_resident(dev, tmp_path):
     cm_a, lg_a = predict_full_patched(res, model, 5, downscale=16, micro_batch=16, return_logits=True, streams=1)
     cm_b, lg_b = predict_full_patched(disk, model, 5, downscale=16, micro_batch=16, return_logits=True, streams=1)
     assert torch.equal(lg_a, lg_b) and torch.equal(cm_a, cm_b)
+    # ... and the streamed mode against the ORACLE pipeline directly (float32: the 1e-4 gate), through a reader that only
+    # serves regions (no whole-layer access at all) and counts what it is asked for
+    class CountingReader:
+        def __init__(self, a):
+            self._a, self.reads, self.rows = a, 0, 0
+        def _assert_layer(self, layer):
+            assert layer == 1
+        def layer_size(self, layer):
+            return self._a.shape[0], self._a.shape[1]
+        def get_region_from_layer(self, layer, p0, p1):
+            self.reads += 1
+            self.rows += p1[0] - p0[0]
+            return self._a[p0[0]:p1[0], p0[1]:p1[1], :]
+    rd = CountingReader(host)
+    disk2 = FullImageDenseSampler(rd, mode=SamplerExecutionMode.ONDISK_MULTIPROC, **kw)
+    m32 = get_model(5, "f32")
+    m32.load_state_dict(oracle.state_dict())
+    m32.to(dev).eval()
+    want_logits, want_canvas, want_map = _oracle_pipeline(host, 128, 96, 8, 16, oracle)
+    cm_c, lg_c = predict_full_patched(disk2, m32, 5, downscale=16, micro_batch=16, return_logits=True, streams=1)
+    assert np.abs(lg_c.cpu().numpy() - want_logits).max() <= 1e-4
+    top2 = np.sort(want_canvas, axis=2)[:, :, -2:]
+    decided = (top2[:, :, 1] - top2[:, :, 0]) > 1e-3
+    assert np.array_equal(cm_c.cpu().numpy()[decided], want_map[decided])
+    n_rows = len(np.unique(disk2.origins[:, 0]))
+    assert rd.reads == n_rows and rd.rows == n_rows * 128        # one P-row strip per tile row, nothing read twice
+
+
+def test_dedupe_padding_option(dev):
+    """`dedupe_padding=True` (opt-in) leaves the corner tile's padding duplicates out of the accumulation; the
+    default reproduces the reference, which accumulates them (predict_full_patched.py:49-54)."""
+    from deephisto_amd.examples.predict_full_patched import predict_full_patched
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    from deephisto_amd.patch_samplers.full_samplers import FullImageDenseSampler
+    host = synth.synth_slide(1000, 1300, 2)
+    oracle = oracle_net.seeded_model(9, 5, perturb_bn=True).eval()
+    model = get_model(5)
+    model.load_state_dict(oracle.state_dict())
+    model.to(dev).eval()
+    smp = FullImageDenseSampler(host, layer=1, patch_size=256, batch_size=16, stride=256, device=dev)   # 24 unique + 8 padded
+    assert smp.n_tiles == 24 and len(smp.origins) == 32
+    cm_ref, lg = predict_full_patched(smp, model, 5, downscale=16, return_logits=True)
+    cm_ded = predict_full_patched(smp, model, 5, downscale=16, dedupe_padding=True)
+    o, l = smp.origins, lg.cpu().numpy()
+    assert np.array_equal(cm_ref.cpu().numpy(), tiling.class_map(tiling.accumulate_logits(1000, 1300, 5, 16, 256, o, l)))
+    assert np.array_equal(cm_ded.cpu().numpy(), tiling.class_map(tiling.accumulate_logits(1000, 1300, 5, 16, 256, o[:24], l[:24])))
 
 
 def test_bf16_pipeline_class_map_gate(dev):
