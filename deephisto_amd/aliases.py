@@ -29,6 +29,7 @@ ALIASES = {
     "models.patch_cls_simple.utils": "deephisto_amd.models.patch_cls_simple.utils",
     "examples": "deephisto_amd.examples",
     "examples.predict_full_patched": "deephisto_amd.examples.predict_full_patched",
+    "examples.sample_full_dense": "deephisto_amd.examples.sample_full_dense",
     "anno": "deephisto_amd.anno",
     "anno.utils": "deephisto_amd.anno.utils",
     "utils": "deephisto_amd.models.patch_cls_simple.utils",

@@ -194,3 +194,15 @@ def test_full_size_grid_and_tiles_properties(dev):
         y, x = o[i]
         want = (synth.synth_region(int(y), int(x), 256, 256, 0).astype(np.float32) / 255).transpose(2, 0, 1)
         assert np.array_equal(got[j].view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+
+
+def test_sample_full_dense_example(dev, capsys):
+    """The caller of examples/sample_full_dense.py on the BASELINE configs[0] geometry (4096^2, 256 / 256 / 64): 4 batches of
+    [64, 256, 256, 3] float32 features and [64, 2] coords, progress 0, 0.25, 0.5, 0.75, then the items/s line."""
+    from deephisto_amd.examples.sample_full_dense import main
+    n, _ = main(["--side", "4096"])
+    out = capsys.readouterr().out.strip().splitlines()
+    assert n == 256
+    shapes = [l for l in out if l.startswith("torch.Size")]
+    assert len(shapes) == 4 and shapes[0].startswith("torch.Size([64, 256, 256, 3]) torch.Size([64, 2]) 0.0")
+    assert shapes[3].endswith("0.75") and out[-1].endswith("items/s")
