@@ -19,6 +19,7 @@ events on the launch stream; `cpu_baseline`: the oracle's CPU restatement of the
 path (NumPy tiling + torch-CPU ResNet-18 fp32) timed on a bounded sample; and, at N = 1,
   `f32`        the same slide in float32 (the mode of north_star's "logits within 1e-4"), its own roofline vs 157.3 TF;
   `train`      BASELINE configs[1]: fused ResNet-18 f32 training steps/s at 64 x 224^2, with a roofline object;
+  `train_bf16` the same network trained on the bf16 engine (bf16 MFMA, f32 master weights): informational, configs[1] is fp32;
   `train_r50`  BASELINE configs[4] per-rank work: ResNet-50 bf16 training steps/s at 64 x 224^2 vs the bf16 MFMA peak;
   `tiler`      the stand-alone gather kernels (a4 path) in GB/s against the 8 TB/s HBM peak;
   `cpu_baselines` sampler-only `generator_torch` (one process, as INMEMORY_SINGLEPROC) and a CPU train step, each with cores.
@@ -368,6 +369,7 @@ def main():
             del slide, smp
             torch.cuda.empty_cache()
             out["train"] = train_leg(dev, args.train_steps, "resnet18", "f32")
+            out["train_bf16"] = train_leg(dev, args.train_steps, "resnet18", "bf16")   # the same network on the bf16 engine (f32 masters)
             out["train_r50"] = train_leg(dev, args.train_steps, "resnet50", "bf16")
         if world > 1:
             out["train_ddp"] = train_ddp

@@ -9,7 +9,7 @@ import torch
 from deephisto_amd.models.patch_cls_simple.model import get_model
 ARCH = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
 dev = torch.device("cuda:0")
-m = (get_model(5, "f32") if ARCH == "resnet18" else get_model(5, "bf16", arch=ARCH)).to(dev).train()
+m = (get_model(5, "f32") if ARCH == "resnet18" else get_model(5, "bf16", arch=ARCH.replace("bf16", ""))).to(dev).train()
 x = torch.rand(64, 3, 224, 224, device=dev)
 y = torch.randint(0, 5, (64,), device=dev)
 for _ in range(3):
