@@ -254,3 +254,24 @@ def test_full_size_fused_bf16_properties(dev):
     assert np.isfinite(lg).all()
     canvas = tiling.accumulate_logits(side, side, 5, 16, P, o, lg)
     assert np.array_equal(cmap.cpu().numpy(), tiling.class_map(canvas))
+
+
+def test_rnd_sampler_generator_torch_ondisk_equals_resident(dev, tmp_path):
+    """FullImageRndSampler.generator_torch in ONDISK_MULTIPROC mode (full_samplers.py:237-262 reads every patch from the file; it
+    raised here in round 1): same global-NumPy-RNG stream, so the batches must equal the resident mode's bit for bit (raw 0..255
+    floats, no /255)."""
+    from deephisto_amd.patch_samplers.full_samplers import FullImageRndSampler, SamplerExecutionMode
+    host = synth.synth_slide(800, 900, 12)
+    path = tmp_path / "slide.npy"
+    np.save(path, host)
+    kw = dict(layer=1, patch_size=96, batch_size=8, dense_level=1, speedup=16, device=dev)
+    np.random.seed(4)
+    a = list(FullImageRndSampler(host, mode=SamplerExecutionMode.INMEMORY_SINGLEPROC, **kw).generator_torch())
+    np.random.seed(4)
+    b = list(FullImageRndSampler(path, mode=SamplerExecutionMode.ONDISK_MULTIPROC, **kw).generator_torch())
+    assert len(a) == len(b) > 3
+    for (fa, ca, ra), (fb, cb, rb) in zip(a, b):
+        assert torch.equal(fa, fb) and torch.equal(ca, cb) and ra == rb
+        assert fa.dtype == torch.float32 and tuple(fa.shape) == (8, 96, 96, 3) and float(fa.max()) > 1.5
+    y, x = int(a[0][1][0, 0]), int(a[0][1][0, 1])
+    np.testing.assert_array_equal(a[0][0][0].cpu().numpy(), host[y:y + 96, x:x + 96].astype(np.float32))
