@@ -70,6 +70,7 @@ SIGNATURES = {
     "dh_debug_wgrad_bf16": (C.c_int, [_p, _p, _p] + [_i32] * 8 + [_p]),
     "dh_debug_conv_bn_act": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i32] * 9 + [_p]),
     "dh_debug_stem_out": (C.c_int, [_p, _i64, _i32, _p, _p]),
+    "dh_debug_stem_pool_bf16": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _p, _p]),
     "dh_debug_wgrad_f32": (C.c_int, [_p, _p, _p] + [_i32] * 8 + [_p]),
     "dh_debug_stem_wgrad_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     "dh_debug_dgrad_f32": (C.c_int, [_p, _p, _p, _p] + [_i32] * 7 + [_p]),

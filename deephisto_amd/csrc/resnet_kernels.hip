@@ -953,6 +953,37 @@ int run_conv(const ConvLayer& L, const void* in, const void* res, void* out, int
   return DH_EINVAL;
 }
 
+// fused bf16 stem (conv1 + bn1 + relu + maxpool) of `B` tiles -> channel-blocked [image][2][H2][W2][32] bf16
+int launch_stem_pool(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t slide_h, int64_t slide_w,
+                     const int32_t* yx, int B, int P, void* out, hipStream_t st) {
+  const int H1 = (P + 6 - 7) / 2 + 1, H2 = (H1 + 2 - 3) / 2 + 1;
+  StemPoolParams sp;
+  sp.x_nchw = x; sp.slide = slide; sp.yx = yx; sp.row_bytes = slide_w * 3; sp.slide_bytes = slide_h * slide_w * 3;
+  sp.w = net->convs[0].w_dev; sp.scale = net->convs[0].scale_dev; sp.shift = net->convs[0].shift_dev; sp.out = out;
+  sp.B = B; sp.P = P; sp.Hc = H1; sp.Wc = H1; sp.Hp = H2; sp.Wp = H2;
+  sp.tiles_y = (H2 + SP_PR - 1) / SP_PR; sp.tiles_x = (H2 + SP_PC - 1) / SP_PC;
+  sp.nstrips = B * sp.tiles_x;                 // a strip = one image x 15 pooled columns, swept top to bottom
+  const int grid = std::min(768, sp.nstrips);  // persistent: three 4-wave workgroups per CU
+  sp.iters = ((sp.nstrips + grid - 1) / grid) * sp.tiles_y;
+  int arc;
+  if ((arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_pool_kernel<true, false>), SP_LDS)) ||
+      (arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_pool_kernel<true, true>), SP_LDS)) ||
+      (arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_pool_kernel<false, false>), SP_LDS))) return arc;
+  sp.stamps = nullptr;
+  if (g_stamps_on && slide) {
+    if (!g_stamps_dev) {
+      DH_HIP(hipMalloc((void**)&g_stamps_dev, 64 * sizeof(unsigned long long)));
+      DH_HIP(hipMemset(g_stamps_dev, 0, 64 * sizeof(unsigned long long)));
+    }
+    sp.stamps = g_stamps_dev + 8 * 7;
+  }
+  if (slide && sp.stamps) hipLaunchKernelGGL((stem_pool_kernel<true, true>), dim3(grid), dim3(SP_T), SP_LDS, st, sp);
+  else if (slide) hipLaunchKernelGGL((stem_pool_kernel<true, false>), dim3(grid), dim3(SP_T), SP_LDS, st, sp);
+  else hipLaunchKernelGGL((stem_pool_kernel<false, false>), dim3(grid), dim3(SP_T), SP_LDS, st, sp);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
 template <typename T>
 int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t slide_h, int64_t slide_w,
                  const int32_t* yx, int64_t n64, int P, float* logits, hipStream_t st) {
@@ -978,30 +1009,7 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
 
   if constexpr (sizeof(T) == 2) {
     // bf16: fused stem + BN + ReLU + maxpool (persistent, weights resident in LDS), straight into bufA
-    StemPoolParams sp;
-    sp.x_nchw = x; sp.slide = slide; sp.yx = yx; sp.row_bytes = slide_w * 3; sp.slide_bytes = slide_h * slide_w * 3;
-    sp.w = net->convs[0].w_dev; sp.scale = net->convs[0].scale_dev; sp.shift = net->convs[0].shift_dev; sp.out = bufA;
-    sp.B = B; sp.P = P; sp.Hc = H1; sp.Wc = H1; sp.Hp = H2; sp.Wp = H2;
-    sp.tiles_y = (H2 + SP_PR - 1) / SP_PR; sp.tiles_x = (H2 + SP_PC - 1) / SP_PC;
-    sp.nstrips = B * sp.tiles_x;                 // a strip = one image x 15 pooled columns, swept top to bottom
-    const int grid = std::min(768, sp.nstrips);  // persistent: three 4-wave workgroups per CU
-    sp.iters = ((sp.nstrips + grid - 1) / grid) * sp.tiles_y;
-    int arc;
-    if ((arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_pool_kernel<true, false>), SP_LDS)) ||
-        (arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_pool_kernel<true, true>), SP_LDS)) ||
-        (arc = ensure_dyn_lds(reinterpret_cast<const void*>(&stem_pool_kernel<false, false>), SP_LDS))) return arc;
-    sp.stamps = nullptr;
-    if (g_stamps_on && slide) {
-      if (!g_stamps_dev) {
-        DH_HIP(hipMalloc((void**)&g_stamps_dev, 64 * sizeof(unsigned long long)));
-        DH_HIP(hipMemset(g_stamps_dev, 0, 64 * sizeof(unsigned long long)));
-      }
-      sp.stamps = g_stamps_dev + 8 * 7;
-    }
-    if (slide && sp.stamps) hipLaunchKernelGGL((stem_pool_kernel<true, true>), dim3(grid), dim3(SP_T), SP_LDS, st, sp);
-    else if (slide) hipLaunchKernelGGL((stem_pool_kernel<true, false>), dim3(grid), dim3(SP_T), SP_LDS, st, sp);
-    else hipLaunchKernelGGL((stem_pool_kernel<false, false>), dim3(grid), dim3(SP_T), SP_LDS, st, sp);
-    DH_LAUNCH_CHECK();
+    if (int rc = launch_stem_pool(net, x, slide, slide_h, slide_w, yx, B, P, bufA, st)) return rc;
   } else {
   // stem
   {
@@ -1250,6 +1258,35 @@ extern "C" int dh_debug_stem_out(dh_resnet18* net, int64_t n, int32_t P, float* 
     hipLaunchKernelGGL((to_f32_kernel<__bf16>), dim3(1024), dim3(256), 0, st, static_cast<const __bf16*>(net->ws), out_dev, elems);
   DH_LAUNCH_CHECK();
   return DH_OK;
+}
+
+namespace {
+__global__ void blocked_to_nhwc_f32_kernel(const __bf16* in, float* out, int64_t n, int hw) {   // [n][2][hw][32] -> [n][hw][64]
+  const int64_t total = n * hw * 64;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % 64);
+    const int64_t px = (i / 64) % hw, b = i / 64 / hw;
+    out[i] = (float)in[((b * 2 + c / 32) * hw + px) * 32 + c % 32];
+  }
+}
+}  // namespace
+
+extern "C" int dh_debug_stem_pool_bf16(dh_resnet18* net, const uint8_t* slide_dev, int64_t slide_h, int64_t slide_w,
+                                       const int32_t* yx_dev, int64_t n, int32_t P, float* out_dev, void* stream) {
+  DH_REQUIRE(net && net->finalized && net->dtype == DH_DTYPE_BF16, "debug stem pool: needs a finalized bf16 network");
+  DH_REQUIRE(slide_dev && yx_dev && out_dev && n > 0 && n <= (1 << 20) && P >= 32 && P <= 1024, "debug stem pool: bad arguments");
+  hipStream_t st = dh::as_stream(stream);
+  const int H1 = (P + 6 - 7) / 2 + 1, H2 = (H1 + 2 - 3) / 2 + 1;
+  void* tmp = nullptr;
+  DH_HIP(hipMalloc(&tmp, (size_t)n * H2 * H2 * 64 * 2));
+  int rc = launch_stem_pool(net, nullptr, slide_dev, slide_h, slide_w, yx_dev, (int)n, P, tmp, st);
+  if (!rc) {
+    hipLaunchKernelGGL(blocked_to_nhwc_f32_kernel, dim3(1024), dim3(256), 0, st, static_cast<const __bf16*>(tmp), out_dev, n, H2 * H2);
+    if (hipGetLastError() != hipSuccess) rc = DH_EHIP;
+    (void)hipStreamSynchronize(st);
+  }
+  (void)hipFree(tmp);
+  return rc;
 }
 
 // ---------------------------------------------------------------------------

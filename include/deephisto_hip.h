@@ -244,6 +244,10 @@ int dh_debug_conv_bn_act(const void* in_dev, const float* w_host, const float* s
                          int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t ks, int32_t stride,
                          int32_t relu, int32_t dtype, void* stream);
 int dh_debug_stem_out(dh_resnet18* net, int64_t n, int32_t patch, float* out_dev, void* stream);
+/* dh_debug_stem_pool_bf16: the fused bf16 stem (conv1 + bn1 + relu + maxpool, models/patch_cls_simple/model.py:6 = the first four
+ * modules of torchvision's resnet18) of n tiles read from the uint8 slide, as float32 NHWC [n][H2][W2][64]; synchronises. */
+int dh_debug_stem_pool_bf16(dh_resnet18* net, const uint8_t* slide_dev, int64_t slide_h, int64_t slide_w, const int32_t* yx_dev,
+                            int64_t n, int32_t patch, float* out_dev, void* stream);
 /* Backward building blocks of the float32 training engine, one at a time, exactly as dh_resnet18_backward launches them
  * (all tensors float32 on the device, activations NHWC; each call allocates its own scratch and synchronises):
  *   wgrad       dW[cout][cin][ks][ks] from x [B][Hi][Wi][cin] and dz [B][Ho][Wo][cout]; mode 1 forces the per-tap kernel

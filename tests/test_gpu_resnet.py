@@ -167,3 +167,41 @@ def test_large_launch_matches_small_launches(dev, dtype, P, n):
     small = torch.cat([model.forward_tiles(slide, o_dev[i:i + 7].contiguous(), P) for i in range(0, n, 7)])
     assert torch.equal(big, small)
     assert bool(torch.isfinite(big).all()) and float(big.abs().max()) > 0
+
+
+@pytest.mark.parametrize("P,side", [(256, 700), (224, 700), (96, 300), (100, 300), (64, 64)])
+def test_fused_bf16_stem_pool_every_pixel(dev, P, side):
+    """The fused bf16 stem (conv 7x7/2 + BN + ReLU + maxpool 3x3/2, one persistent kernel reading the uint8 slide) against a
+    torch-CPU restatement with the SAME roundings (pixels k/255 -> bf16, weights -> bf16, f32 accumulation, BN in f32, one
+    rounding to bf16): every pooled pixel of every tile, tiles in the slide's corners included (the first and the last byte of
+    the allocation lie inside their windows).  Only the f32 summation order differs, so values agree to one bf16 ulp and
+    nearly all are identical."""
+    from deephisto_amd._lib import check, lib
+    oracle = oracle_net.seeded_model(77, 5, perturb_bn=True).eval()
+    model = _hip_model(oracle, dev, "bf16")
+    host = synth.synth_slide(side, side + 37 if side > P else side, seed=P)
+    H, W = host.shape[:2]
+    rng = np.random.default_rng(P)
+    o = [[0, 0], [H - P, W - P], [0, W - P], [H - P, 0]]
+    o += [[int(rng.integers(0, H - P + 1)), int(rng.integers(0, W - P + 1))] for _ in range(9)]
+    o = np.array(o, np.int32)
+    n = len(o)
+    model(torch.zeros(1, 3, P, P, device=dev))                         # finalises the handle
+    H2 = ((P - 1) // 2 + 1 - 1) // 2 + 1
+    got = torch.empty((n, H2, H2, 64), dtype=torch.float32, device=dev)
+    slide = torch.from_numpy(host).to(dev)
+    check(lib().dh_debug_stem_pool_bf16(model._handle, slide.data_ptr(), H, W, torch.from_numpy(o).to(dev).data_ptr(), n, P,
+                                        got.data_ptr(), None), "dh_debug_stem_pool_bf16")
+    x = torch.from_numpy(tiling.features_nchw_predictor(host, o, P)).bfloat16().float()
+    with torch.no_grad():
+        z = F.conv2d(x, oracle.conv1.weight.bfloat16().float(), None, 2, 3)
+        bn = oracle.bn1
+        sc = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        sh = bn.bias - bn.running_mean * sc
+        y = F.relu((z * sc[None, :, None, None] + sh[None, :, None, None]).bfloat16().float())
+        want = F.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1)
+    g = got.cpu()
+    assert g.shape == want.shape
+    err = (g - want).abs()
+    assert bool((err <= 2.0 ** -7 * want.abs().clamp_min(2.0 ** -6)).all()), f"max err {float(err.max())}"
+    assert float((g == want).float().mean()) > 0.98
