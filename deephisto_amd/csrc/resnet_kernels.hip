@@ -615,6 +615,27 @@ void pack_stem_weights(const float* w, int esz, std::vector<uint8_t>& out) {
   }
 }
 
+// Stem weights for the fused bf16 stem (stem_pool.inc): [k-step (11)][cout half][lane][8], two kernel rows per three k-steps
+// (sp_kslot maps a k-slot to its kernel row and 24-slot row image; slot s carries W[co][c][kh][kw] for s-1 = 3kw + c in [0,21)).
+void pack_stem_pool_weights(const float* w, std::vector<uint8_t>& out) {
+  out.assign((size_t)SP_WBYTES, 0);
+  size_t o = 0;
+  for (int ks = 0; ks < SP_KS; ++ks)
+    for (int mt = 0; mt < 2; ++mt)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          int kh, sl;
+          sp_kslot(ks, l >> 5, j, &kh, &sl);
+          float v = 0.f;
+          if (kh >= 0 && sl >= 1 && sl <= 21) {
+            const int co = mt * 32 + (l & 31), kw = (sl - 1) / 3, c = (sl - 1) % 3;
+            v = w[((size_t)(co * 3 + c) * 7 + kh) * 7 + kw];
+          }
+          const uint16_t hb = host_bf16(v);
+          memcpy(&out[o], &hb, 2); o += 2;
+        }
+}
+
 // Optional in-library timing of the dominant kernel (3x3 stride-1 conv): HIP events on
 // the launch stream around sampled launches, summed by dh_profile_stop (bench.py's
 // `roofline.achieved`).  Off by default; costs nothing when off.
@@ -958,6 +979,7 @@ int launch_stem_pool(dh_resnet18* net, const float* x, const uint8_t* slide, int
                      const int32_t* yx, int B, int P, void* out, hipStream_t st) {
   const int H1 = (P + 6 - 7) / 2 + 1, H2 = (H1 + 2 - 3) / 2 + 1;
   StemPoolParams sp;
+  DH_REQUIRE(!slide || slide_w < (1 << 24), "stem: slide rows of %lld pixels are not supported (< 2^24)", (long long)slide_w);
   sp.x_nchw = x; sp.slide = slide; sp.yx = yx; sp.row_bytes = slide_w * 3; sp.slide_bytes = slide_h * slide_w * 3;
   sp.w = net->convs[0].w_dev; sp.scale = net->convs[0].scale_dev; sp.shift = net->convs[0].shift_dev; sp.out = out;
   sp.B = B; sp.P = P; sp.Hc = H1; sp.Wc = H1; sp.Hp = H2; sp.Wp = H2;
@@ -1139,7 +1161,8 @@ extern "C" int dh_resnet18_finalize(dh_resnet18* net, void* stream) {
     DH_REQUIRE(w && g && b && m && v, "resnet18 finalize: parameters of '%s' / '%s' are not all set",
                c.name.c_str(), c.bn.c_str());
     std::vector<uint8_t> packed;
-    if (i == 0) pack_stem_weights(w->data(), esz, packed);
+    if (i == 0 && esz == 2) pack_stem_pool_weights(w->data(), packed);   // bf16 inference runs the fused stem only
+    else if (i == 0) pack_stem_weights(w->data(), esz, packed);
     else pack_conv_weights(w->data(), c.cout, c.cin, c.ks, esz, packed);
     int rc = upload(packed, &c.w_dev);
     if (rc) return rc;
