@@ -299,11 +299,14 @@ class ResNet18HIP(nn.Module):
             red = BucketReducer(self.flat_gradients(x.device), group)
             cb = BUCKET_CB(lambda bucket, off, cnt, _user: red.on_bucket(bucket, off, cnt))
             check(lib().dh_resnet18_set_buckets(self._handle, int(bucket_bytes), cb, None, None), "dh_resnet18_set_buckets")
-        check(lib().dh_resnet18_backward(self._handle, dl.data_ptr(), st), "dh_resnet18_backward")
-        if red is not None:
-            red.finish()
-            self.overlap_log = red.log
-            check(lib().dh_resnet18_set_buckets(self._handle, 0, None, None, None), "dh_resnet18_set_buckets")
+        try:
+            check(lib().dh_resnet18_backward(self._handle, dl.data_ptr(), st), "dh_resnet18_backward")
+            if red is not None:
+                red.finish()
+                self.overlap_log = red.log
+        finally:
+            if red is not None:   # never leave the library holding a callback into a dead trampoline
+                check(lib().dh_resnet18_set_buckets(self._handle, 0, None, None, None), "dh_resnet18_set_buckets")
         self._adam_t = getattr(self, "_adam_t", 0) + 1
         check(lib().dh_resnet18_adam_step(self._handle, lr, betas[0], betas[1], eps, self._adam_t, st), "dh_resnet18_adam_step")
         self._native_ahead = True

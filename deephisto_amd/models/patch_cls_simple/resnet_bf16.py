@@ -145,11 +145,14 @@ class Train2Engine:
         check(lib().dh_train2_set_buckets(self.handle, int(bucket_bytes), self._cb, None, C.byref(n)), "dh_train2_set_buckets")
         return red
 
-    def _finish_overlap(self, red):
-        red.finish()
-        self.overlap_log = red.log
-        check(lib().dh_train2_set_buckets(self.handle, 0, None, None, None), "dh_train2_set_buckets")
-        self._cb = None
+    def _finish_overlap(self, red, ok=True):
+        try:
+            if ok:
+                red.finish()
+                self.overlap_log = red.log
+        finally:   # never leave the library holding a callback into a dead trampoline
+            check(lib().dh_train2_set_buckets(self.handle, 0, None, None, None), "dh_train2_set_buckets")
+            self._cb = None
 
     def train_step(self, x, labels, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None, bucket_bytes=DEFAULT_BUCKET_BYTES):
         from .model import ce_loss
@@ -161,7 +164,12 @@ class Train2Engine:
         st = self._stream(x.device)
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         red = self._arm_overlap(x.device, group, bucket_bytes) if world > 1 else None
-        check(lib().dh_train2_backward(self.handle, dl.data_ptr(), st), "dh_train2_backward")
+        try:
+            check(lib().dh_train2_backward(self.handle, dl.data_ptr(), st), "dh_train2_backward")
+        except Exception:
+            if red is not None:
+                self._finish_overlap(red, ok=False)
+            raise
         if red is not None:
             self._finish_overlap(red)
         check(lib().dh_train2_adam_step(self.handle, lr, betas[0], betas[1], eps, 0, st), "dh_train2_adam_step")

@@ -169,7 +169,7 @@ def test_large_launch_matches_small_launches(dev, dtype, P, n):
     assert bool(torch.isfinite(big).all()) and float(big.abs().max()) > 0
 
 
-@pytest.mark.parametrize("P,side", [(256, 700), (224, 700), (96, 300), (100, 300), (64, 64)])
+@pytest.mark.parametrize("P,side", [(256, 700), (224, 700), (96, 300), (100, 300), (64, 64), (330, 700), (32, 90)])
 def test_fused_bf16_stem_pool_every_pixel(dev, P, side):
     """The fused bf16 stem (conv 7x7/2 + BN + ReLU + maxpool 3x3/2, one persistent kernel reading the uint8 slide) against a
     torch-CPU restatement with the SAME roundings (pixels k/255 -> bf16, weights -> bf16, f32 accumulation, BN in f32, one
