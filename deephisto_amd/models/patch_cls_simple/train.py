@@ -11,8 +11,13 @@ What moved to the GPU: the step itself (forward, CrossEntropy, backward, Adam: H
 `dh_tile_gather_aug`), and the running loss / accuracy sums (accumulated on the device, read
 once per epoch instead of four host syncs per step, train.py:174-180).
 
-Not reproduced: the ImageFolder test loop and the JPEG plots (train.py:253-301; disk I/O and
-matplotlib, out of scope).  The data source is any object with `device_batches(batch_size,
+The test set is the reference's: `--extract_test` cuts `test.samples_per_class` JPEG patches per class
+from the test slides into `test.dir` (`prepare_test_patches`, train.py:41-56), and every epoch ends
+with the ImageFolder test loop (train.py:109-111, 253-283: class folders and files in torchvision's
+sorted order, `ToTensor` = uint8 / 255 in float32, batches of `batch_size`, unshuffled) run through the
+HIP model, and the loss / accuracy plots `loss.jpg` / `acc.jpg` (train.py:285-301) when matplotlib is
+importable.  A missing `test.dir` skips the test loop (the reference would stop in ImageFolder).
+The data source is any object with `device_batches(batch_size,
 n_batches)`: `AnnoRegionRndSampler` over `cfg["dataset"]["folder"]` when that folder exists (as
 in the reference, train.py:93-103; `.psi` images need the third-party psimage package), else a
 closed-form synthetic slide with rectangular regions (`RectRegionRndSampler`, BASELINE configs[1]).
@@ -26,7 +31,8 @@ import torch
 
 from . import utils
 from .model import ce_loss, get_model
-from ...patch_samplers.region_samplers import AnnoRegionRndSampler, RectRegionRndSampler, synthetic_regions
+from ...patch_samplers.region_samplers import (AnnoRegionRndSampler, RectRegionRndSampler, extract_and_save_subset,
+                                               synthetic_regions)
 
 
 def _rank_world():
@@ -46,6 +52,78 @@ def _synthetic_sampler(cfg, device):
     return RectRegionRndSampler(slide, regions, layer=cfg["dataset"]["layer"], patch_size=cfg["dataset"]["patch_size"],
                                 patches_from_one_region=cfg["dataset"]["patches_from_one_region"], seed=_rank_world()[0],
                                 device=device)   # data parallel: every rank draws its own stream of patches
+
+
+def prepare_test_patches(cfg, img_anno_paths=None, device="cuda"):
+    """train.py:41-56: (re)create `test.dir` with `test.samples_per_class` JPEG patches per class from the test slides."""
+    import shutil
+
+    if img_anno_paths is None:
+        img_anno_paths = utils.get_img_ano_paths(ds_folder=Path(cfg["dataset"]["folder"]), sample="test")
+    out_dir = Path(cfg["test"]["dir"])
+    if out_dir.exists() and out_dir.is_dir():
+        shutil.rmtree(out_dir)
+    return extract_and_save_subset(img_anno_paths=img_anno_paths, out_folder=out_dir, patch_size=cfg["dataset"]["patch_size"],
+                                   layer=cfg["dataset"]["layer"], patches_per_class=cfg["test"]["samples_per_class"],
+                                   device=device)
+
+
+class TestImageFolder:
+    """The reference's `ImageFolder(root, transform=ToTensor())` + `DataLoader(batch_size, shuffle=False)` (train.py:109-111,
+    253-257) without torchvision: classes = sub-folders in sorted (string) order, samples = the image files of each class
+    in sorted order, a sample = uint8 HWC / 255 as float32 CHW.  The decoded patches stay on the device as uint8."""
+
+    EXT = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
+
+    def __init__(self, root, device):
+        import numpy as np
+        from PIL import Image
+
+        root = Path(root)
+        self.classes = sorted(d.name for d in root.iterdir() if d.is_dir())
+        if not self.classes:
+            raise FileNotFoundError(f"Couldn't find any class folder in {root}.")
+        imgs, labels = [], []
+        for ci, c in enumerate(self.classes):
+            for f in sorted(q for q in (root / c).rglob("*") if q.is_file() and q.suffix.lower() in self.EXT):
+                with Image.open(f) as im:
+                    imgs.append(np.asarray(im.convert("RGB")))
+                labels.append(ci)
+        if not imgs:
+            raise FileNotFoundError(f"Found no valid file for the classes {self.classes}.")
+        self.u8 = torch.from_numpy(np.stack(imgs)).to(device)          # [N, P, P, 3]
+        self.labels = torch.tensor(labels, dtype=torch.int64, device=device)
+        # ToTensor divides on the CPU (correctly rounded); a float division on the GPU may differ in the last bit, so the 256
+        # possible values come from a table computed on the host
+        self._lut = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255)).to(device)
+
+    def __len__(self):
+        return int(self.labels.numel())
+
+    def batches(self, batch_size: int):
+        for b0 in range(0, len(self), batch_size):
+            x = self._lut[self.u8[b0:b0 + batch_size].permute(0, 3, 1, 2).long()].contiguous()             # ToTensor
+            yield x, self.labels[b0:b0 + batch_size]
+
+
+def save_plot(out_dir, train_values, val_values, test_values, title, filename):
+    """train.py:28-38; skipped when matplotlib is not importable."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception:
+        return False
+    plt.figure()
+    plt.plot(train_values, label="train")
+    plt.plot(val_values, label="val")
+    plt.plot(test_values, label="test")
+    plt.title(title)
+    plt.xlabel("Epoch")
+    plt.legend()
+    plt.savefig(Path(out_dir) / filename)
+    plt.close()
+    return True
 
 
 class _PlateauLR:
@@ -92,8 +170,12 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
     model = get_model(cfg["model"]["n_classes"], cfg.get("runtime", {}).get("compute_dtype", "f32"),
                       arch=cfg["model"].get("arch", "resnet18")).to(device)
     sched = _PlateauLR(cfg["training"]["lr"])
-    history = {"train_loss": [], "train_acc": [], "val_loss": [], "val_acc": [], "lr": []}
+    history = {"train_loss": [], "train_acc": [], "val_loss": [], "val_acc": [], "lr": [], "test_loss": [], "test_acc": []}
     best_val_acc = 0.0
+    test_dir = Path(cfg.get("test", {}).get("dir", "")) if cfg.get("test", {}).get("dir") else None
+    test_set = TestImageFolder(test_dir, device) if test_dir is not None and test_dir.is_dir() else None
+    if test_set is None:
+        log("no test folder (run with --extract_test to create it): the test loop is skipped")
     n_epochs = epochs if epochs is not None else cfg["training"]["n_epochs"]
 
     for epoch in range(n_epochs):
@@ -127,8 +209,25 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
             best_val_acc = val_acc
             if rank == 0:
                 torch.save(model.state_dict(), out_dir / "best_model.pth")
-        for k, v in zip(history, (train_loss, train_acc, val_loss, val_acc, lr)):
+        for k, v in zip(("train_loss", "train_acc", "val_loss", "val_acc", "lr"), (train_loss, train_acc, val_loss, val_acc, lr)):
             history[k].append(v)
+
+        # test loop over the JPEG ImageFolder (train.py:251-283), plots (train.py:285-301)
+        if test_set is not None:
+            tloss = torch.zeros((), device=device)
+            tcorrect, nb = torch.zeros((), device=device, dtype=torch.int64), 0
+            for x, labels in test_set.batches(bs):
+                logits = model(x)
+                tloss += ce_loss(logits, labels)
+                tcorrect += (logits.argmax(1) == labels).sum()
+                nb += 1
+            test_loss, test_acc = float(tloss) / nb, int(tcorrect) / len(test_set)
+            history["test_loss"].append(test_loss)
+            history["test_acc"].append(test_acc)
+            log(f"Test Loss: {test_loss:.4f}, Test Acc: {test_acc:.4f}")
+            if rank == 0:
+                save_plot(out_dir, history["train_loss"], history["val_loss"], history["test_loss"], "Loss", "loss.jpg")
+                save_plot(out_dir, history["train_acc"], history["val_acc"], history["test_acc"], "Acc", "acc.jpg")
     return model, history
 
 
@@ -148,10 +247,11 @@ def main(argv=None):
         cfg_path = cwd_cfg if cwd_cfg.exists() else Path(__file__).with_name("config.yaml")
     cfg = utils.load_config(cfg_path)
     if args.extract_test:
-        # train.py:33-56 cuts a test ImageFolder of JPEG patches from the test slides (extract_and_save_subset): host-side
-        # disk I/O outside the hot path; accepted so that the reference's command line keeps working
-        print("--extract_test: the JPEG test-patch extraction is not part of this build (no test ImageFolder is written); "
-              "training proceeds with the train / validation loop")
+        if Path(cfg["dataset"]["folder"]).exists():
+            prepare_test_patches(cfg, device=utils.get_device())        # train.py:312-313
+        else:
+            print(f"--extract_test: dataset folder {cfg['dataset']['folder']} does not exist (synthetic training data): "
+                  "no test patches are cut")
     return train(cfg, epochs=args.epochs)
 
 

@@ -525,3 +525,32 @@ class AnnoRegionDenseSampler:
                     # the image border can be negative or hang over it (region_samplers.py:160-166)
                     x = tiles.gather_tiles_aug(self._bank.slide(region.image_index), o_dev, ps, layout, dtype)
                     yield x, torch.full((len(o),), cls_idx, dtype=torch.int64, device=dev), tiles.tile_coords(o_dev)
+
+
+def extract_and_save_subset(img_anno_paths, out_folder, patch_size: int, layer: int, patches_per_class: int,
+                            intersection: float = 0.95, device="cuda"):
+    """`patches_per_class` JPEG patches per class under `out_folder/<class index>/<n>.jpg` -- the test ImageFolder of
+    models/patch_cls_simple/train.py:41-56 (region_samplers.py:874-909): regions weighted equally, one patch per region,
+    95 % of a patch inside its region, batches of 4.  As in the reference, class index 0 cannot be forced (`cls_idx or random`,
+    region_samplers.py:555, 576): folder "0" receives patches of randomly drawn classes."""
+    from pathlib import Path as _Path
+
+    from PIL import Image
+
+    sampler = AnnoRegionRndSampler(img_anno_paths=img_anno_paths, layer=layer, patch_size=patch_size,
+                                   region_intersection=intersection, region_area_influence=0, patches_from_one_region=1,
+                                   device=device)
+    out_folder = _Path(out_folder)
+    batch_size = 4
+    counts = {}
+    for cls_idx, cls in enumerate(sampler.classes):
+        (out_folder / str(cls_idx)).mkdir(parents=True, exist_ok=True)
+        n = patches_per_class // batch_size
+        count = 0
+        for batch in sampler.structs_generator(batch_size=batch_size, n_batches=n, cls_idx=cls_idx):
+            for patch, _cls in batch:
+                Image.fromarray(np.ascontiguousarray(patch.data)).save(out_folder / str(cls_idx) / f"{count}.jpg")
+                count += 1
+        counts[cls] = count
+    return counts
+

@@ -269,3 +269,62 @@ def test_train_mirror_resnet50_bf16(dev, tmp_path):
     model.load_state_dict(ck)
     got = model.eval()(x.to(dev)).cpu()
     assert float((got - want).abs().max()) <= 5e-2 * max(1.0, float(want.abs().max()))
+
+
+def test_extract_test_patches_and_test_loop(dev, tmp_path):
+    """`--extract_test` path (train.py:41-56 + region_samplers.py:874-909) and the per-epoch ImageFolder test loop
+    (train.py:109-111, 251-301): JPEG patches per class in `test.dir/<class index>/<n>.jpg`, every one of them from inside a
+    region of its class (the classes are colour-coded, JPEG noise is far below the colour distance), then train() with that
+    folder present reports test loss / accuracy per epoch and writes the two plots."""
+    from PIL import Image
+    from deephisto_amd.models.patch_cls_simple.train import TestImageFolder, prepare_test_patches, train
+    from deephisto_amd.patch_samplers.region_samplers import RectRegion, RectRegionRndSampler
+    side = 1200
+    host = synth.synth_slide(side, side, 2) // 8
+    colours = {"AT": (200, 30, 30), "BG": (30, 200, 30), "TUM": (30, 30, 200)}
+    anno, regions = [], []
+    for i, (name, col) in enumerate(colours.items()):
+        y0, y1 = 40 + i * 380, 40 + i * 380 + 330
+        host[y0:y1, 60:1100, :] += np.array(col, dtype=np.uint8)
+        anno.append({"class": name, "vertices": [[60, y0], [1100, y0], [1100, y1], [60, y1]]})
+        regions.append(RectRegion(name, y0, 60, y1, 1100))
+    cfg = {"model": {"n_classes": 3},
+           "training": {"batch_size": 8, "n_epochs": 1, "lr": 1e-3, "save_dir": str(tmp_path / "ck"),
+                        "out_dir": str(tmp_path / "out"), "val_steps": 2},
+           "test": {"dir": str(tmp_path / "test"), "samples_per_class": 12},
+           "dataset": {"folder": "/nonexistent", "layer": 1, "patch_size": 64, "patches_from_one_region": 4}}
+    (tmp_path / "test" / "stale").mkdir(parents=True)                     # an old folder is replaced, not merged
+    np.random.seed(3)
+    counts = prepare_test_patches(cfg, img_anno_paths=[(host, anno)], device=dev)
+    assert counts == {"AT": 12, "BG": 12, "TUM": 12} and not (tmp_path / "test" / "stale").exists()
+    for ci, (name, col) in enumerate(colours.items()):
+        files = sorted((tmp_path / "test" / str(ci)).iterdir())
+        assert [f.name for f in files] == sorted(f"{k}.jpg" for k in range(12))
+        for f in files:
+            im = np.asarray(Image.open(f))
+            assert im.shape == (64, 64, 3)
+            mean = im.reshape(-1, 3).mean(0)
+            dist = {n: np.abs(mean - (np.array(c) + 15)).max() for n, c in colours.items()}   # 95 % of the patch inside a region
+            if ci == 0:
+                # the reference's `c_idx = cls_idx or random` (region_samplers.py:555, 576) cannot force class index 0:
+                # folder "0" receives patches of randomly drawn classes there, and therefore here
+                assert min(dist.values()) < 25
+            else:
+                assert dist[name] < 25
+    ts = TestImageFolder(tmp_path / "test", dev)
+    assert ts.classes == ["0", "1", "2"] and len(ts) == 36
+    xb, yb = next(ts.batches(8))
+    first = np.asarray(Image.open(tmp_path / "test" / "0" / "0.jpg")).astype(np.float32) / 255       # ToTensor
+    assert xb.dtype == torch.float32 and tuple(xb.shape) == (8, 3, 64, 64) and yb.tolist() == [0] * 8
+    np.testing.assert_array_equal(xb[0].cpu().numpy(), first.transpose(2, 0, 1))
+    order = [int(v) for v in sorted(str(k) for k in range(12))]                                       # "0", "1", "10", "11", "2", ...
+    second = np.asarray(Image.open(tmp_path / "test" / "0" / f"{order[2]}.jpg")).astype(np.float32) / 255
+    np.testing.assert_array_equal(xb[2].cpu().numpy(), second.transpose(2, 0, 1))
+    smp = RectRegionRndSampler(host, regions, layer=1, patch_size=64, seed=0, device=dev)
+    lines = []
+    torch.manual_seed(0)
+    model, hist = train(cfg, sampler=smp, epochs=2, steps_per_epoch=30, log=lambda *a: lines.append(" ".join(map(str, a))))
+    assert len(hist["test_loss"]) == 2 and all(np.isfinite(hist["test_loss"]))
+    assert hist["test_acc"][1] > 0.45                                     # folders 1, 2 are learnable (folder 0 is mixed, see above)
+    assert sum(l.startswith("Test Loss:") for l in lines) == 2
+    assert (tmp_path / "out" / "loss.jpg").exists() and (tmp_path / "out" / "acc.jpg").exists()
