@@ -185,14 +185,22 @@ class RegionAnnotation:
             raise RuntimeError("Invalid region shape. It should be (N, 2).")
         if vertices.dtype != np.float64:
             raise RuntimeError("Invalid region dtype. It should be float64.")
-        ring = _pg.as_ccw(vertices if layer == 1 else vertices.copy() / layer)
-        if not _pg.is_simple(ring) or _pg.area(ring) == 0.0:
-            # the reference repairs such rings with shapely's buffer(0) (:68-70); without shapely the region
-            # is rejected here and counted by _parse_annotations as failed, like any other bad region
-            raise RuntimeError("Invalid (self-intersecting or degenerate) polygon.")
-        self.polygon = ring
-        self.area = _pg.area(ring)
-        self.bounds = _pg.bounds(ring)   # (minx, miny, maxx, maxy), shapely's order
+        ring = _pg.as_ccw(_pg.drop_repeats(vertices if layer == 1 else vertices.copy() / layer))
+        if len(ring) >= 3 and _pg.is_simple(ring) and _pg.area(ring) != 0.0:
+            self.polygon = ring           # one counter-clockwise simple ring
+            self.area = _pg.area(ring)
+            self.bounds = _pg.bounds(ring)   # (minx, miny, maxx, maxy), shapely's order
+        else:
+            # "invalid polygon found. Fixing..." (:68-71): shapely's buffer(0), restated in polygon.repair -- the lobes of the
+            # ring that are wound like the ring itself; the region becomes a LIST of simple rings
+            print("invalid polygon found. Fixing...")
+            rings = _pg.repair(ring) if len(ring) >= 3 else []
+            if not rings:
+                raise RuntimeError("Invalid (degenerate) polygon.")
+            self.polygon = rings if len(rings) > 1 else rings[0]
+            self.area = float(sum(_pg.area(r) for r in rings))
+            allv = np.concatenate(rings)
+            self.bounds = _pg.bounds(allv)
 
     def __str__(self) -> str:
         stem = Path(self.file_path).stem if isinstance(self.file_path, (str, Path)) else "array"

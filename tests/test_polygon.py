@@ -74,7 +74,7 @@ def test_overlap_matches_rasterisation(seed):
 def _two_image_annotations():
     a0 = [{"class": "TUM", "vertices": _star(3, cx=600, cy=600, r0=250, r1=500).tolist()},
           {"class": "BG", "vertices": [[100, 1300], [900, 1300], [900, 1900], [100, 1900]]},
-          {"class": "BG", "vertices": [[0, 0], [50, 50], [50, 0], [0, 50]]},            # bow tie: rejected
+          {"class": "BG", "vertices": [[0, 0], [50, 50], [50, 0], [0, 50]]},            # bow tie: repaired (too small to sample)
           {"class": "SKIP", "vertices": [[0, 0], [300, 0], [300, 300], [0, 300]]}]
     a1 = [{"class": "TUM", "vertices": [[200, 200], [1400, 260], [1300, 1500], [260, 1400]]},
           {"class": "LP", "vertices": _star(4, cx=1500, cy=600, r0=200, r1=400).tolist()}]
@@ -90,8 +90,8 @@ def test_region_annotation_and_random_origins():
         RegionAnnotation("img", 0, "TUM", v.astype(np.float32), 1, (2000, 2000))
     with pytest.raises(RuntimeError, match="shape"):
         RegionAnnotation("img", 0, "TUM", v.ravel(), 1, (2000, 2000))
-    with pytest.raises(RuntimeError, match="polygon"):
-        RegionAnnotation("img", 0, "TUM", np.array([[0, 0], [10, 10], [10, 0], [0, 10]], float), 1, (2000, 2000))
+    with pytest.raises(RuntimeError, match="polygon"):      # a ring without area cannot be repaired either
+        RegionAnnotation("img", 0, "TUM", np.array([[0, 0], [10, 10], [20, 20]], float), 1, (2000, 2000))
     np.random.seed(7)
     c1 = reg._extract_patch_coords_rnd(224, 12, 0.75)
     np.random.seed(7)
@@ -123,7 +123,8 @@ def test_sampler_weights_stream_and_records(tmp_path):
     smp = AnnoRegionRndSampler([(img0, p0), (img1, a1)], layer=1, patch_size=128, classes=["TUM", "BG", "LP"],
                                patches_from_one_region=4, region_area_influence=0.5)
     assert smp.classes == ["BG", "LP", "TUM"]
-    assert {c: len(r) for c, r in smp.regions.items()} == {"TUM": 2, "BG": 1, "LP": 1}      # bow tie + SKIP dropped
+    assert {c: len(r) for c, r in smp.regions.items()} == {"TUM": 2, "BG": 2, "LP": 1}      # SKIP dropped; the bow tie is repaired
+    assert sorted(r.area for r in smp.regions["BG"])[0] == pytest.approx(625.0)               # ... to its 25 x 50 / 2 lobe
     assert [sorted(d) for d in smp.regions_per_image] == [["BG", "TUM"], ["LP", "TUM"]]
     for w in list(smp._reg_w_all.values()) + [smp._img_w_all] + list(smp._img_w.values()):
         assert abs(float(np.sum(w)) - 1.0) < 1e-12
@@ -168,3 +169,39 @@ def test_sampler_weights_stream_and_records(tmp_path):
     assert got and [c for _, c in got] == sorted(c for _, c in got)
     bg = [(p.pos_y, p.pos_x) for p, c in got if c == 0]
     assert bg == [(y, x) for y in range(1300, 1900 - 128, 128) for x in range(100, 900 - 128, 128)]
+
+
+
+def test_self_crossing_rings_are_repaired_like_buffer0():
+    """region_samplers.py:68-71: an invalid polygon is replaced by `polygon.buffer(0)`.  The restatement (polygon.repair) nodes
+    the ring at its crossings / touches and keeps the lobes wound like the ring (the turn at its highest vertex): analytic
+    cases, then a RegionAnnotation on a crossed ring samples only inside the kept lobe.  Parity unpinned (no shapely)."""
+    from deephisto_amd.patch_samplers.region_samplers import RegionAnnotation
+    # bow tie: the lobe with the ring's highest vertex survives, the mirror lobe (opposite winding) does not
+    r = pg.repair(np.array([[0, 0], [10, 10], [10, 0], [0, 10]], float))
+    assert len(r) == 1 and pg.area(r[0]) == pytest.approx(25.0)
+    assert sorted(map(tuple, r[0].tolist())) == [(5.0, 5.0), (10.0, 0.0), (10.0, 10.0)]
+    # a ring that only TOUCHES itself at a vertex: two lobes of one orientation, both kept
+    r = pg.repair(np.array([[0, 0], [0, 2], [1, 1], [2, 2], [2, 0], [1, 1]], float))
+    assert len(r) == 2 and sum(pg.area(x) for x in r) == pytest.approx(2.0)
+    # a hand-drawn glitch: the last stroke doubles back over the outline (T-junction + tiny flag)
+    g = np.array([[0, 0], [100, 0], [100, 100], [2, 100], [0, 98], [3, 103], [0, 100]], float)
+    r = pg.repair(g)
+    assert sum(pg.area(x) for x in r) == pytest.approx(9998.0 + 3.0) and all(pg.is_simple(x) for x in r)
+    # simple rings pass through unchanged; repeated consecutive points are not an invalidity
+    sq = np.array([[0, 0], [4, 0], [4, 0], [4, 3], [0, 3], [0, 0]], float)
+    assert pg.is_simple(pg.as_ccw(pg.drop_repeats(sq))) and pg.area(pg.repair(sq)[0]) == pytest.approx(12.0)
+    # overlap with rectangles is additive over the kept rings: against a rasterisation of "inside a kept lobe"
+    big = np.array([[100, 100], [900, 900], [900, 100], [100, 900]], float)      # crossed: right lobe kept
+    rings = pg.repair(big)
+    assert len(rings) == 1 and pg.area(rings[0]) == pytest.approx(0.5 * 800 * 400)
+    ys, xs = np.mgrid[0:1000, 0:1000] + 0.5
+    inside = (xs >= 500) & (np.abs(ys - 500) <= xs - 500) & (xs <= 900)          # the right triangle
+    for (x, y, sd) in [(600, 400, 200), (450, 450, 100), (100, 100, 300), (700, 650, 150)]:
+        want = inside[y:y + sd, x:x + sd].sum()
+        assert float(pg.overlap_area_square(rings, x, y, sd)) == pytest.approx(want, abs=sd * 1.5)
+    reg = RegionAnnotation("img", 0, "TUM", big, layer=1, layer_size=(1000, 1000))
+    assert reg.area == pytest.approx(160000.0) and reg.bounds == (500.0, 100.0, 900.0, 900.0)
+    np.random.seed(3)
+    for y, x in reg._extract_patch_coords_rnd(96, 10, 0.75):
+        assert inside[y:y + 96, x:x + 96].mean() > 0.7
