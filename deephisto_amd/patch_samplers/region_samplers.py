@@ -344,18 +344,19 @@ class AnnoRegionRndSampler:
 
     # ---- weights (region_samplers.py:339-482) ------------------------------------------------------------
     def _calc_area_weights(self, areas, area_influence: float):
-        assert -1 <= area_influence <= 1
-        areas_inv = [1 / a for a in areas]
-        w_proportional = np.array(areas) / sum(areas)
-        w_inv_proportional = np.array(areas_inv) / sum(areas_inv)
-        w_default = np.ones(len(areas), dtype=np.float64) / len(areas)
+        """Mixing weights of regions (or images) from their areas (region_samplers.py:339-378): uniform at influence 0, pulled
+        towards the area shares for positive influence and towards the inverse-area shares for negative influence, renormalised.
+        The sums are Python's left-to-right `sum`, as in the reference, so the weights are the same floats."""
+        if not -1 <= area_influence <= 1:
+            raise AssertionError("area influence must lie in [-1, 1]")
+        n = len(areas)
+        uniform = np.full(n, 1.0, dtype=np.float64) / n
         if area_influence == 0:
-            return w_default
-        if area_influence > 0:
-            w = w_default + (w_proportional - w_default) * area_influence
-        else:
-            w = w_default + (w_inv_proportional - w_default) * (-area_influence)
-        return w / sum(w)
+            return uniform
+        pull = list(areas) if area_influence > 0 else [1 / a for a in areas]
+        share = np.array(pull) / sum(pull)
+        mixed = uniform + (share - uniform) * abs(area_influence)
+        return mixed / sum(mixed)
 
     def _calc_weights(self, regions, regions_per_image):
         infl = self.region_area_influence
