@@ -1,0 +1,52 @@
+"""One process per GPU: process-group setup for the two multi-GPU entry points.
+
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P -m
+models.patch_cls_simple.train` (BASELINE configs[4]: data-parallel training, RCCL all-reduce of gradient buckets) and
+`... -m examples.predict_full_patched` (configs[3]: tile ranges sharded over the ranks, ONE RCCL all-gather of logits).
+The reference is single-process (`models/patch_cls_simple/train.py:304-315`, `examples/predict_full_patched.py:128-177`);
+these helpers are what turns its two `__main__` blocks into per-rank programs.
+
+Order matters on ROCm: the rank binds its GPU (`torch.cuda.set_device(LOCAL_RANK)`) and joins the group
+(`init_process_group("nccl", device_id=...)`: backend "nccl" IS RCCL) BEFORE any other GPU call, so no rank ever creates a
+context on cuda:0 by accident.  `DH_DIST_BACKEND=gloo` selects the CPU backend (tests, rehearsals on a one-GPU box together
+with `DH_SHARE_GPU=1`, which maps every rank to cuda:0).
+"""
+from __future__ import annotations
+
+import os
+
+
+def env_world() -> tuple[int, int, int]:
+    """(rank, world, local_rank) from the launcher's environment (1 process when absent)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_from_env():
+    """Join the process group torch.distributed.run describes.  Returns (rank, world, device_index or None, owned):
+    `owned` says this call created the group (the caller then ends with `finalize(owned)`).  Single process: no-op."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world, local = env_world()
+    if world <= 1:
+        return 0, 1, (torch.cuda.current_device() if torch.cuda.is_available() else None), False
+    if dist.is_initialized():   # an embedding program (bench.py, a test) already did it
+        return dist.get_rank(), dist.get_world_size(), (torch.cuda.current_device() if torch.cuda.is_available() else None), False
+    backend = os.environ.get("DH_DIST_BACKEND", "nccl")
+    dev_index = None
+    if backend == "nccl" or os.environ.get("DH_SHARE_GPU") == "1":
+        dev_index = 0 if os.environ.get("DH_SHARE_GPU") == "1" else local
+        torch.cuda.set_device(dev_index)           # before anything else touches a GPU
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))   # RCCL over xGMI
+    else:
+        dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size(), dev_index, True
+
+
+def finalize(owned: bool) -> None:
+    import torch.distributed as dist
+
+    if owned and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

@@ -310,3 +310,95 @@ def perform_and_save_visualizations(img, anno_dsc, pred, out_dir: Path = Path(".
         Image.fromarray(img_np).save(out_dir / f"{stem}.jpg", quality=95)
         Image.fromarray(ov_np).save(out_dir / f"{stem}_overlay.jpg", quality=95)
     return mask_np, img_np, ov_np
+
+
+KNOWN_COLORS = {   # predict_full_patched.py:139-148
+    "AT": (245, 119, 34),    # orange
+    "BG": (153, 255, 255),   # cyan
+    "LP": (64, 170, 72),     # green
+    "MM": (255, 0, 0),       # red
+    "TUM": (33, 67, 156),    # blue
+}
+
+
+def main(argv=None, model=None):
+    """The reference's `__main__` (predict_full_patched.py:128-177) as a per-rank program.
+
+    The reference hard-codes the slide path, `./output/best_model.pth`, layer 2, downscale 16, patch 224, batch 64 and
+    (dense branch, :165-167) stride 112; those are the defaults of the flags below.  The dense branch is the multi-GPU
+    path: under `python -m torch.distributed.run --nproc-per-node N -m examples.predict_full_patched ...` every rank
+    binds its GPU, joins the RCCL group, takes its contiguous tile range and the logits are exchanged with one
+    all-gather (`predict_full_patched`); rank 0 writes the three JPEGs.  `--random_sampler` keeps the reference's
+    default branch (`FullImageRndSampler` through `ImagePredictorPatched.process()`, single process).
+    `--synthetic H W` runs on a closed-form slide when no .psi file / psimage is at hand; `--weights ''` = random init.
+    `model`: an injected module (tests)."""
+    import argparse
+
+    from ..anno.utils import AnnoDescription
+    from ..distributed import finalize, init_from_env
+    from ..models.patch_cls_simple import utils
+    from ..patch_samplers.full_samplers import FullImageRndSampler, SamplerExecutionMode
+
+    ap = argparse.ArgumentParser(description=main.__doc__.splitlines()[0])
+    ap.add_argument("--image", default="/home/xubiker/dev/PATH-DT-MSU.WSS2/images/test/test_01.psi")
+    ap.add_argument("--synthetic", type=int, nargs=2, metavar=("H", "W"), default=None)
+    ap.add_argument("--weights", default="./output/best_model.pth")
+    ap.add_argument("--layer", type=int, default=2)
+    ap.add_argument("--downscale_vis", type=int, default=16)
+    ap.add_argument("--patch_size", type=int, default=224)
+    ap.add_argument("--batch_size", type=int, default=64)
+    ap.add_argument("--stride", type=int, default=112)
+    ap.add_argument("--random_sampler", action="store_true", default=False)
+    ap.add_argument("--ondisk", action="store_true", help="SamplerExecutionMode.ONDISK_MULTIPROC: stream row strips")
+    ap.add_argument("--compute_dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--out_dir", default="./output/")
+    ap.add_argument("--no_visualizations", action="store_true")
+    args = ap.parse_args(argv)
+
+    rank, world, _dev_index, owned = init_from_env()   # binds the rank's GPU before any other GPU call
+    try:
+        import torch.distributed as dist
+        device = utils.get_device()
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if model is None:
+            if device.type != "cuda":
+                raise RuntimeError("predict_full_patched runs on the GPU only (HIP kernels); no CPU fallback")
+            if args.weights:
+                model = load_model(args.weights, device, args.compute_dtype)
+            else:
+                torch.manual_seed(0)   # the same random init on every rank
+                model = get_model(n_classes=5, compute_dtype=args.compute_dtype).to(device).eval()
+        anno_dsc = AnnoDescription.with_known_colors(KNOWN_COLORS)
+        n_cls = len(anno_dsc.anno_classes)
+        if args.synthetic is not None:
+            img = tiles.synth_slide(args.synthetic[0], args.synthetic[1], 0, device)
+            stem = f"synthetic_{args.synthetic[0]}x{args.synthetic[1]}"
+        else:
+            img, stem = Path(args.image), Path(args.image).stem
+        mode = SamplerExecutionMode.ONDISK_MULTIPROC if args.ondisk else SamplerExecutionMode.INMEMORY_SINGLEPROC
+        if args.random_sampler:
+            if world > 1:
+                raise RuntimeError("--random_sampler draws tiles from a running coverage map (one process); "
+                                   "the dense sampler is the multi-GPU path")
+            smp = FullImageRndSampler(img, layer=args.layer, patch_size=args.patch_size, batch_size=args.batch_size,
+                                      mode=mode, device=device)
+            pred = ImagePredictorPatched((smp.h, smp.w), patch_sampler=smp.generator(),
+                                         batch_predictor=lambda patches: batch_predictor(patches, model, device),
+                                         anno=anno_dsc, layer=args.layer, downscale=args.downscale_vis, device=device).process()
+        else:
+            smp = FullImageDenseSampler(img, layer=args.layer, patch_size=args.patch_size, batch_size=args.batch_size,
+                                        mode=mode, stride=args.stride, device=device)
+            pred = predict_full_patched(smp, model, n_cls, downscale=args.downscale_vis)   # sharded when world > 1
+        if rank == 0 and not args.no_visualizations:
+            src = img if isinstance(img, torch.Tensor) or not smp.resident else smp.data_device
+            perform_and_save_visualizations(src, anno_dsc, pred, out_dir=Path(args.out_dir), stem=stem, device=device)
+        if world > 1:
+            dist.barrier()
+        return pred
+    finally:
+        finalize(owned)
+
+
+if __name__ == "__main__":
+    main()

@@ -223,6 +223,13 @@ class ResNet18HIP(nn.Module):
                 seen[name] = key
         if dirty:
             check(lib().dh_resnet18_train_repack(self._handle, stream), "dh_resnet18_train_repack")
+        if getattr(self, "_buffers_dirty", False):   # load_state_dict: running statistics -> library
+            for name, buf in self.named_buffers():
+                if not name.endswith("num_batches_tracked"):
+                    t = buf.detach().to(torch.float32).contiguous()
+                    check(lib().dh_resnet18_train_tensor(self._handle, name.encode(), 2, t.data_ptr(), t.numel(), 1, stream),
+                          f"push {name}")
+            self._buffers_dirty = False
 
     def _native_forward_train(self, x, pull_stats=True):
         n, p = int(x.shape[0]), int(x.shape[2])
@@ -332,6 +339,18 @@ class ResNet18HIP(nn.Module):
     def state_dict(self, *args, **kwargs):
         self.pull_parameters()
         return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        """The loaded tensors win over whatever the library holds after fused `train_step` calls (which leave the
+        library's masters newer than the nn.Parameters): nothing is pulled back over them, the eval-mode copy is
+        rebuilt, and the next training forward pushes parameters (version counters) and running statistics."""
+        self._native_ahead, self._stats_pending = False, 0
+        if self._engine2 is not None:
+            self._engine2.native_ahead, self._engine2._stats_pending = False, 0
+        out = super().load_state_dict(*args, **kwargs)
+        self._synced = None
+        self._buffers_dirty = True
+        return out
 
     def forward_tiles(self, slide: torch.Tensor, origins_dev: torch.Tensor, patch: int) -> torch.Tensor:
         """Fused gather + /255 + forward straight from the uint8 slide in HBM."""

@@ -143,10 +143,30 @@ class _PlateauLR:
         return self.lr
 
 
-def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
+def _mean_over_ranks(*values):
+    """Epoch metrics averaged over the ranks, so that every replica takes the same learning-rate and checkpoint decisions."""
+    import torch.distributed as dist
+
+    if _rank_world()[1] == 1:
+        return values
+    t = torch.tensor(values, dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t)
+    return tuple((t / _rank_world()[1]).tolist())
+
+
+def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print, model=None):
+    """`model` / `sampler`: injected objects with `train_step(x, labels, lr=)` / `device_batches(bs, n, flips=)` (tests of the
+    multi-process wiring run stubs on CPU tensors); by default the HIP model and the GPU samplers, which need a GPU."""
     device = utils.get_device()
-    log(f"Using device: {device}")
-    if device.type != "cuda":
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())   # under torch.distributed.run: the rank's own GPU
+    rank, world = _rank_world()
+    if rank != 0:
+        log = lambda *_a, **_k: None   # noqa: E731  (rank 0 reports, as it alone writes the files)
+    log(f"Using device: {device}" + (f"  ({world} ranks, data parallel)" if world > 1 else ""))
+    if device.type != "cuda" and model is None:
         raise RuntimeError("deephisto_amd trains on the GPU only (HIP kernels); no CPU fallback")
     Path(cfg["training"]["save_dir"]).mkdir(parents=True, exist_ok=True)
     out_dir = Path(cfg["training"]["out_dir"])
@@ -154,6 +174,9 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
 
     if sampler is None:
         folder = Path(cfg["dataset"]["folder"])
+        if world > 1:   # the annotation samplers draw from the global NumPy RNG (as the reference's do): one stream per rank
+            import numpy as np
+            np.random.seed(20240 + rank)
         if folder.exists():   # the reference's data source (train.py:93-103); .psi files need the psimage package
             sampler = AnnoRegionRndSampler(utils.get_img_ano_paths(folder, sample="train"),
                                            patch_size=cfg["dataset"]["patch_size"], layer=cfg["dataset"]["layer"],
@@ -166,9 +189,9 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
     bs = cfg["training"]["batch_size"]
     # `model.arch: resnet50` selects the backbone of BASELINE configs[4] (bf16 engine); under torchrun (one process per GPU)
     # train_step averages the gradients over the ranks (bucketed all-reduce overlapped with backward) and rank 0 writes the files
-    rank, world = _rank_world()
-    model = get_model(cfg["model"]["n_classes"], cfg.get("runtime", {}).get("compute_dtype", "f32"),
-                      arch=cfg["model"].get("arch", "resnet18")).to(device)
+    if model is None:
+        model = get_model(cfg["model"]["n_classes"], cfg.get("runtime", {}).get("compute_dtype", "f32"),
+                          arch=cfg["model"].get("arch", "resnet18")).to(device)
     sched = _PlateauLR(cfg["training"]["lr"])
     history = {"train_loss": [], "train_acc": [], "val_loss": [], "val_acc": [], "lr": [], "test_loss": [], "test_acc": []}
     best_val_acc = 0.0
@@ -188,7 +211,7 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
             loss_sum += loss
             correct += (logits.argmax(1) == labels).sum()
             total += labels.numel()
-        train_loss, train_acc = float(loss_sum) / steps_per_epoch, int(correct) / total
+        train_loss, train_acc = _mean_over_ranks(float(loss_sum) / steps_per_epoch, int(correct) / total)
         log(f"Epoch {epoch + 1}/{n_epochs}  Train Loss: {train_loss:.4f}, Train Acc: {train_acc:.4f}")
 
         # validation: same sampler, same augmentations, eval-mode BN, no update (train.py:190-236)
@@ -201,7 +224,7 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print):
             vloss += ce_loss(logits, labels)                          # dh_ce_loss: CrossEntropyLoss(mean), train.py:117
             vcorrect += (logits.argmax(1) == labels).sum()
             vtotal += labels.numel()
-        val_loss, val_acc = float(vloss) / val_steps, int(vcorrect) / vtotal
+        val_loss, val_acc = _mean_over_ranks(float(vloss) / val_steps, int(vcorrect) / vtotal)
         log(f"Val Loss: {val_loss:.4f}, Val Acc: {val_acc:.4f}")
         lr = sched.step(val_loss)
         log(f"Current Learning Rate: {lr:.6f}")
@@ -239,6 +262,7 @@ def main(argv=None):
     parser.add_argument("--extract_test", action="store_true", default=False)
     parser.add_argument("--config", default=None)
     parser.add_argument("--epochs", type=int, default=None)
+    parser.add_argument("--steps_per_epoch", type=int, default=200)   # train.py:142 hard-codes 200
     args = parser.parse_args(argv)
     if args.config is not None:
         cfg_path = Path(args.config)
@@ -246,13 +270,22 @@ def main(argv=None):
         cwd_cfg = Path("./models/patch_cls_simple/config.yaml")
         cfg_path = cwd_cfg if cwd_cfg.exists() else Path(__file__).with_name("config.yaml")
     cfg = utils.load_config(cfg_path)
-    if args.extract_test:
-        if Path(cfg["dataset"]["folder"]).exists():
-            prepare_test_patches(cfg, device=utils.get_device())        # train.py:312-313
-        else:
-            print(f"--extract_test: dataset folder {cfg['dataset']['folder']} does not exist (synthetic training data): "
-                  "no test patches are cut")
-    return train(cfg, epochs=args.epochs)
+    # one process per GPU under torch.distributed.run: bind the rank's GPU and join the RCCL group before any other GPU call
+    from ...distributed import finalize, init_from_env
+    rank, world, _dev, owned = init_from_env()
+    try:
+        if args.extract_test and rank == 0:
+            if Path(cfg["dataset"]["folder"]).exists():
+                prepare_test_patches(cfg, device=utils.get_device())        # train.py:312-313
+            else:
+                print(f"--extract_test: dataset folder {cfg['dataset']['folder']} does not exist (synthetic training data): "
+                      "no test patches are cut")
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()   # the test folder exists before any rank opens it
+        return train(cfg, epochs=args.epochs, steps_per_epoch=args.steps_per_epoch)
+    finally:
+        finalize(owned)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,81 @@
+"""GPU: the two command-line entry points as per-rank programs.
+`examples.predict_full_patched` (reference `__main__`: examples/predict_full_patched.py:128-177, dense branch) and
+`models.patch_cls_simple.train` (models/patch_cls_simple/train.py:304-315), single process and as two ranks under
+torch.distributed.run sharing cuda:0 over gloo (a one-GPU box; on a node the same code runs one rank per GPU over RCCL)."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(args, nproc, tmp_path, extra_env=None):
+    env = dict(os.environ, PYTHONPATH=f"{REPO / 'compat'}:{REPO}", **(extra_env or {}))
+    if nproc == 1:
+        cmd = [sys.executable, "-m", *args]
+    else:
+        env.update(DH_DIST_BACKEND="gloo", DH_SHARE_GPU="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), "-m", *args]
+    r = subprocess.run(cmd, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r
+
+
+def test_predict_cli_single_and_two_ranks_agree(built_lib, tmp_path):
+    """python -m examples.predict_full_patched on a synthetic slide: the class map of the sharded 2-rank run (one all-gather of
+    logits) equals the single-process map bit for bit; rank 0 writes the three JPEGs of :81-113."""
+    from deephisto_amd.examples.predict_full_patched import main
+    pred1 = main(["--synthetic", "1500", "1300", "--weights", "", "--patch_size", "224", "--stride", "112", "--batch_size", "16",
+                  "--out_dir", str(tmp_path / "one")]).cpu().numpy()
+    assert pred1.shape == (1500 // 16, 1300 // 16) and pred1.dtype == np.int64
+    for f in ("synthetic_1500x1300_mask.jpg", "synthetic_1500x1300.jpg", "synthetic_1500x1300_overlay.jpg"):
+        assert (tmp_path / "one" / f).stat().st_size > 0
+    # the same through the module path of the reference, as two ranks; the map is saved by a tiny wrapper below
+    (tmp_path / "run2.py").write_text(
+        "import sys, numpy as np\n"
+        "from examples.predict_full_patched import main\n"
+        "import os\n"
+        "pred = main(sys.argv[1:])\n"
+        "np.save(f'pred_{os.environ.get(\"RANK\", \"0\")}.npy', pred.cpu().numpy())\n")
+    args = ["--synthetic", "1500", "1300", "--weights", "", "--patch_size", "224", "--stride", "112", "--batch_size", "16",
+            "--out_dir", str(tmp_path / "two")]
+    env = dict(os.environ, PYTHONPATH=f"{REPO / 'compat'}:{REPO}", DH_DIST_BACKEND="gloo", DH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(tmp_path / "run2.py"), *args]
+    r = subprocess.run(cmd, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for k in range(2):
+        assert np.array_equal(np.load(tmp_path / f"pred_{k}.npy"), pred1), f"rank {k}"
+    assert (tmp_path / "two" / "synthetic_1500x1300_overlay.jpg").stat().st_size > 0
+
+
+def test_train_cli_two_ranks_resnet50(built_lib, tmp_path):
+    """python -m models.patch_cls_simple.train under torch.distributed.run (2 ranks): configs[4]'s program -- ResNet-50 bf16,
+    bucketed all-reduce inside train_step -- runs an epoch and rank 0 leaves a loadable checkpoint."""
+    import yaml
+    cfg = {"dataset": {"folder": str(tmp_path / "nope"), "layer": 1, "patch_size": 64, "patches_from_one_region": 2},
+           "model": {"n_classes": 5, "arch": "resnet50"}, "runtime": {"synthetic_slide": 2048},
+           "training": {"save_dir": str(tmp_path / "save"), "out_dir": str(tmp_path / "out"), "batch_size": 8, "lr": 1e-4,
+                        "n_epochs": 1, "val_steps": 1}}
+    (tmp_path / "cfg.yaml").write_text(yaml.safe_dump(cfg))
+    r = _run(["models.patch_cls_simple.train", "--config", str(tmp_path / "cfg.yaml"), "--steps_per_epoch", "3"], 2, tmp_path)
+    assert "2 ranks, data parallel" in r.stdout and r.stdout.count("Epoch 1/1") == 1
+    sd = torch.load(tmp_path / "out" / "best_model.pth", weights_only=True) if (tmp_path / "out" / "best_model.pth").exists() else None
+    # the checkpoint is written when validation accuracy beats 0: with 5 classes and 8 samples that may not happen on every
+    # seed, so only its loadability is asserted when present
+    if sd is not None:
+        assert "layer4.2.conv3.weight" in sd and sd["fc.weight"].shape == (5, 2048)

@@ -328,3 +328,45 @@ def test_extract_test_patches_and_test_loop(dev, tmp_path):
     assert hist["test_acc"][1] > 0.45                                     # folders 1, 2 are learnable (folder 0 is mixed, see above)
     assert sum(l.startswith("Test Loss:") for l in lines) == 2
     assert (tmp_path / "out" / "loss.jpg").exists() and (tmp_path / "out" / "acc.jpg").exists()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_load_state_dict_after_fused_step_wins(dtype):
+    """after `train_step` the library's masters are newer than the nn.Parameters; a
+    `load_state_dict(sd0)` must not be undone by the lazy pull-back.  train_step -> load_state_dict(sd0) -> eval()(x)
+    equals a fresh model holding sd0 (parameters AND running statistics), and training resumes from sd0."""
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    from oracle import resnet18 as o18
+    dev = torch.device("cuda:0")
+    sd0 = {k: v.clone() for k, v in o18.seeded_model(5, 5, perturb_bn=True).state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(8, 3, 64, 64, generator=g).to(dev)
+    y = torch.randint(0, 5, (8,), generator=g).to(dev)
+
+    fresh = get_model(5, dtype)
+    fresh.load_state_dict(sd0)
+    fresh.to(dev).eval()
+    want = fresh(x).cpu()
+
+    m = get_model(5, dtype)
+    m.load_state_dict(sd0)
+    m.to(dev).train()
+    for _ in range(2):
+        m.train_step(x, y, lr=1e-2)
+    m.load_state_dict(sd0)
+    got = m.eval()(x).cpu()
+    assert torch.equal(got, want), f"max diff {float((got - want).abs().max())}"
+    after = m.state_dict()
+    for k, v in sd0.items():
+        assert torch.equal(after[k].cpu(), v), k
+    # training resumes from sd0: the first step's logits equal those of a fresh model's first step
+    m.train()
+    fresh.train()
+    _, l1 = m.train_step(x, y, lr=1e-2)
+    _, l2 = fresh.train_step(x, y, lr=1e-2)
+    assert torch.equal(l1.cpu(), l2.cpu())
+    # ... and so do the running statistics both then hold
+    a, b = m.state_dict(), fresh.state_dict()
+    for k in a:
+        if "running" in k:
+            assert torch.equal(a[k].cpu(), b[k].cpu()), k
