@@ -67,6 +67,11 @@ SIGNATURES = {
     "dh_train2_adam_step": (C.c_int, [_p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
     "dh_train2_debug_act": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _p]),
     "dh_debug_gemm1x1_bf16": (C.c_int, [_p, _p, _p, _p, _i64] + [_i32] * 8 + [_p]),
+    "dh_debug_gemm1x1_fused_bf16": (C.c_int, [_p] * 7 + [_i64] + [_i32] * 8 + [_p]),
+    "dh_debug_bn2_bf16": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _i64, _i32, _p]),
+    "dh_debug_maxpool2_bf16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dh_debug_upsample2_add_bf16": (C.c_int, [_p, _p] + [_i32] * 6 + [_p]),
+    "dh_debug_avgpool_fc_dgrad2": (C.c_int, [_p, _p, _p] + [_i32] * 4 + [_p]),
     "dh_debug_wgrad_bf16": (C.c_int, [_p, _p, _p] + [_i32] * 8 + [_p]),
     "dh_debug_conv_bn_act": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i32] * 9 + [_p]),
     "dh_debug_stem_out": (C.c_int, [_p, _i64, _i32, _p, _p]),

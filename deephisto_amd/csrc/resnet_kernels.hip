@@ -1357,4 +1357,5 @@ extern "C" int dh_debug_stamps(int32_t enable, unsigned long long* out64_host) {
 
 #include "train.inc"
 #include "train2_kernels.inc"
+#include "gemm1x1.inc"
 #include "train2.inc"

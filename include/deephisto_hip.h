@@ -230,6 +230,25 @@ int dh_train2_debug_act(dh_train2* net, const char* conv_name, int32_t what, flo
 int dh_debug_gemm1x1_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const uint16_t* res_dev, uint16_t* out_dev, int64_t M,
                           int32_t N, int32_t K, int32_t stride, int32_t Ho, int32_t Wo, int32_t Hi, int32_t Wi, int32_t repeat,
                           void* stream);
+/* dh_debug_gemm1x1_fused_bf16: the 1x1 GEMM with its fused epilogues -- + res, ReLU mask of another tensor (output zeroed where
+ * mask_dev <= 0), batch statistics of the bf16-rounded output (mean / invstd as the BN finalize writes them; both or neither). */
+int dh_debug_gemm1x1_fused_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const uint16_t* res_dev, const uint16_t* mask_dev,
+                                uint16_t* out_dev, float* mean_dev, float* invstd_dev, int64_t M, int32_t N, int32_t K, int32_t stride,
+                                int32_t Ho, int32_t Wo, int32_t Hi, int32_t Wi, int32_t repeat, void* stream);
+/* dh_debug_bn2_bf16: the bf16 engine's batch-norm kernels on caller data ([rows][C] channels-last, bf16 bits): forward with batch
+ * statistics (y, saved mean / invstd), and, when dy_dev is given, backward (dz, dgamma, dbeta; relu_mode 0 none, 1 mask from y,
+ * 2 mask recomputed from z; g_out_dev: the masked gradient, may be null). */
+int dh_debug_bn2_bf16(const uint16_t* z_dev, const uint16_t* res_dev, const float* gamma_dev, const float* beta_dev, int32_t relu,
+                      uint16_t* y_dev, float* mean_dev, float* invstd_dev, const uint16_t* dy_dev, int32_t relu_mode, uint16_t* dz_dev,
+                      uint16_t* g_out_dev, float* dgamma_dev, float* dbeta_dev, int64_t rows, int32_t C, void* stream);
+/* The remaining HBM-bound kernels of the bf16 engine on caller data: max-pool 3x3/2 forward (+ backward when dy_dev is given),
+ * the strided add of the downsample branch's gradient, and the average-pool + fc backward. */
+int dh_debug_maxpool2_bf16(const uint16_t* x_dev, uint16_t* y_dev, const uint16_t* dy_dev, uint16_t* dx_dev, int32_t B, int32_t Hi,
+                           int32_t Wi, int32_t C, void* stream);
+int dh_debug_upsample2_add_bf16(const uint16_t* t_dev, uint16_t* dx_dev, int32_t B, int32_t Ho, int32_t Wo, int32_t Hi, int32_t Wi,
+                                int32_t C, void* stream);
+int dh_debug_avgpool_fc_dgrad2(const float* dlogits_dev, const float* w_dev, uint16_t* dx_dev, int32_t B, int32_t HW, int32_t C,
+                               int32_t n_cls, void* stream);
 int dh_debug_wgrad_bf16(const uint16_t* dz_dev, const uint16_t* x_dev, float* dw_dev, int32_t B, int32_t Hi, int32_t Wi,
                         int32_t cin, int32_t cout, int32_t ks, int32_t stride, int32_t repeat, void* stream);
 

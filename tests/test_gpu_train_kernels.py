@@ -215,3 +215,169 @@ def test_wgrad_bf16_kernels(dev, ks, stride, cin, cout, B, H):
     if ks == 3:
         for t in ((0, 0), (0, 2), (2, 0), (2, 2), (1, 1)):
             assert _rel(dw.cpu()[:, :, t[0], t[1]], want[:, :, t[0], t[1]]) <= TOL, t
+
+
+@pytest.mark.parametrize("M,N,K", [(777, 64, 64), (3136, 256, 1024), (12544, 128, 256), (128 * 129 + 5, 64, 128), (50176, 128, 64)])
+def test_gemm1x1_fused_epilogues(dev, M, N, K):
+    """The fused epilogues of the ring GEMM (gemm1x1.inc).  Statistics: mean / invstd of the bf16-ROUNDED output (what the BN of
+    train.py's model normalises) against float64 over the kernel's own output: 1e-6 relative (f32 partials of <= 128 values,
+    double column sums in the finalize launch).
+    Mask: the output is zero exactly where the mask tensor is <= 0, and untouched elsewhere (bit-equal to the unmasked run).
+    Repeating the launch gives the same bits."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev).bfloat16().contiguous()
+    w = _bf(torch.randn(N, K, generator=g) * (1.0 / K) ** 0.5).to(dev).bfloat16().contiguous()
+    res = _bf(torch.randn(M, N, generator=g)).to(dev).bfloat16().contiguous()
+    msk = torch.relu(torch.randn(M, N, generator=g)).to(dev).bfloat16().contiguous()
+    msk.view(-1)[::7] = -0.0     # a negative zero masks like a zero
+    geo = (1, 1, 1, 1, 1)
+    fn = lib().dh_debug_gemm1x1_fused_bf16
+    plain = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    check(lib().dh_debug_gemm1x1_bf16(a.data_ptr(), w.data_ptr(), None, plain.data_ptr(), M, N, K, *geo, 1, None), "gemm")
+    # statistics
+    out = torch.empty_like(plain)
+    mean = torch.empty(N, dtype=torch.float32, device=dev)
+    invstd = torch.empty_like(mean)
+    for rep in (1, 3):
+        mean.fill_(float("nan")); invstd.fill_(float("nan"))
+        check(fn(a.data_ptr(), w.data_ptr(), None, None, out.data_ptr(), mean.data_ptr(), invstd.data_ptr(), M, N, K, *geo, rep, None), "fused")
+        assert torch.equal(out, plain)
+        z = out.double()
+        mu, var = z.mean(0), z.var(0, unbiased=False)
+        assert float(((mean.double() - mu).abs() / (z.abs().mean(0) + 1e-12)).max()) <= 1e-6
+        assert float((invstd.double() * torch.sqrt(var + 1e-5) - 1).abs().max()) <= 1e-6
+        if rep == 1:
+            first = (mean.clone(), invstd.clone())
+        else:
+            assert torch.equal(mean, first[0]) and torch.equal(invstd, first[1])
+    # residual + mask
+    both = torch.empty_like(plain)
+    unmasked = torch.empty_like(plain)
+    check(fn(a.data_ptr(), w.data_ptr(), res.data_ptr(), None, unmasked.data_ptr(), None, None, M, N, K, *geo, 1, None), "fused")
+    check(fn(a.data_ptr(), w.data_ptr(), res.data_ptr(), msk.data_ptr(), both.data_ptr(), None, None, M, N, K, *geo, 1, None), "fused")
+    keep = msk.float() > 0
+    assert torch.equal(both[keep], unmasked[keep])
+    assert int((both[~keep].view(torch.int16) != 0).sum()) == 0
+
+
+# ---- bf16 engine: the HBM-bound kernels one by one (VERDICT r2 item 2) ---------------------------------------------------
+def _bf16_ulp_close(got, want64, slack=1.0):
+    """`got` (bf16 tensor) equals float64 `want64` up to the final rounding to bf16: |err| <= slack * 2^-8 * |want| + tiny."""
+    g = got.float().cpu().double()
+    return bool(((g - want64).abs() <= slack * 2.0 ** -8 * want64.abs() + 1e-30).all())
+
+
+@pytest.mark.parametrize("rows,C,relu,with_res,mode", [(3136, 64, 1, False, 2), (50176, 64, 1, False, 2), (784 * 3, 256, 1, True, 1),
+                                                       (784 * 3, 256, 1, True, 0), (196 * 7 + 3, 1024, 0, False, 0), (49 * 5, 2048, 1, True, 1),
+                                                       (200704, 128, 1, False, 2), (12544, 512, 1, True, 1)])
+def test_bn2_bf16_kernels(dev, rows, C, relu, with_res, mode):
+    """bf16 engine BN: statistics (per-workgroup partial sums + finalize launch), apply (+ identity)(+ ReLU), backward reduce + apply, against torch
+    autograd in float64 on the same bf16 operands.  Saved mean / invstd and dgamma / dbeta (float32 results of double
+    column sums in a fixed order): relative 1e-5.  y and dz are bf16: equal to the float64 result up to the final rounding (one bf16 ulp, 2^-8
+    relative; dz: the coefficients are float32, so 2 ulp).  mode 0 = no mask in the backward kernels (dy pre-masked by the
+    test, as the dgrad GEMM's epilogue does it in the engine), 1 = mask from y, 2 = mask recomputed from z.  Two runs: equal bits."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(rows + C + mode)
+    z = _bf(torch.randn(rows, C, generator=g) * (torch.rand(C, generator=g) + 0.5) + torch.randn(C, generator=g))
+    res = _bf(torch.randn(rows, C, generator=g)) if with_res else None
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    dy = _bf(torch.randn(rows, C, generator=g) * 1e-3)
+    z64 = z.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mu, var = z64.mean(0), z64.var(0, unbiased=False)
+    yb = (z64 - mu) / torch.sqrt(var + 1e-5) * g64 + b64
+    if with_res:
+        yb = yb + res.double()
+    y64 = torch.relu(yb) if relu else yb
+    zd = z.to(dev).bfloat16().contiguous()
+    rd = res.to(dev).bfloat16().contiguous() if with_res else None
+    gd, bd = gamma.to(dev), beta.to(dev)
+    outs = []
+    for _ in range(2):
+        y = torch.empty(rows, C, dtype=torch.bfloat16, device=dev)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        dz = torch.empty_like(y)
+        gout = torch.empty_like(y) if mode == 1 else None
+        dgam, dbet = torch.empty_like(mean), torch.empty_like(mean)
+        if relu and mode == 0:     # the engine hands such a BN a gradient that is already masked
+            dyd = (dy * (y64.detach() > 0).float()).to(dev).bfloat16().contiguous()
+        else:
+            dyd = dy.to(dev).bfloat16().contiguous()
+        check(lib().dh_debug_bn2_bf16(zd.data_ptr(), rd.data_ptr() if with_res else None, gd.data_ptr(), bd.data_ptr(), relu, y.data_ptr(),
+                                      mean.data_ptr(), invstd.data_ptr(), dyd.data_ptr(), mode if relu else 0, dz.data_ptr(),
+                                      gout.data_ptr() if gout is not None else None, dgam.data_ptr(), dbet.data_ptr(), rows, C, None), "bn2")
+        outs.append((y, mean, invstd, dz, dgam, dbet))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)                                            # fixed-order sums: no run-to-run difference
+    y, mean, invstd, dz, dgam, dbet = outs[0]
+    assert float((mean.cpu().double() - mu.detach()).abs().max()) <= 1e-6 * float(z.abs().max())
+    assert float((invstd.cpu().double() * torch.sqrt(var.detach() + 1e-5) - 1).abs().max()) <= 1e-6
+    # y: the engine normalises with float32 coefficients, then rounds to bf16
+    yg = y.float().cpu().double()
+    assert float((yg - y64.detach()).abs().max()) <= 2.0 ** -8 * float(y64.abs().max()) + 1e-6
+    assert _rel(yg, y64.detach()) <= 3e-3
+    # backward against autograd: dL = sum(y * dy)
+    (y64 * dy.double()).sum().backward()
+    assert _rel(dgam.cpu(), g64.grad) <= 1e-5 and _rel(dbet.cpu(), b64.grad) <= 1e-5
+    dzg = dz.float().cpu().double()
+    assert _rel(dzg, z64.grad) <= 3e-3
+    if gout is not None:
+        assert torch.equal(gout.float().cpu(), (dy * (y.float().cpu() > 0).float()))
+
+
+@pytest.mark.parametrize("B,H,C", [(3, 112, 64), (2, 57, 64), (5, 14, 128)])
+def test_maxpool2_bf16_kernels(dev, B, H, C):
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B * H + C)
+    x = _bf(torch.randn(B, C, H, H, generator=g))
+    x[:, :, 1::7, 2::5] = x[:, :, 0:-1:7, 1:-1:5][:, :, :x[:, :, 1::7, 2::5].shape[2], :x[:, :, 1::7, 2::5].shape[3]]   # ties
+    x64 = x.double().requires_grad_(True)
+    y64 = F.max_pool2d(x64, 3, 2, 1)
+    dy = _bf(torch.randn(y64.shape, generator=g))
+    (y64 * dy.double()).sum().backward()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev).bfloat16()
+    Ho = y64.shape[2]
+    y = torch.empty(B, Ho, Ho, C, dtype=torch.bfloat16, device=dev)
+    dx = torch.empty(B, H, H, C, dtype=torch.bfloat16, device=dev)
+    check(lib().dh_debug_maxpool2_bf16(xd.data_ptr(), y.data_ptr(), dyd.data_ptr(), dx.data_ptr(), B, H, H, C, None), "maxpool2")
+    assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), y64.detach().float())
+    want = x64.grad            # sums of <= 4 bf16 terms, rounded to bf16 once
+    got = dx.float().cpu().permute(0, 3, 1, 2).double()
+    assert float((got - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
+    assert _rel(got, want) <= 3e-3
+
+
+def test_upsample2_add_and_avgpool_fc_dgrad_bf16(dev):
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(77)
+    B, Ho, Hi, C = 3, 14, 28, 256
+    t = _bf(torch.randn(B, Ho, Ho, C, generator=g))
+    dx0 = _bf(torch.randn(B, Hi, Hi, C, generator=g))
+    dxd = dx0.to(dev).bfloat16().contiguous()
+    td = t.to(dev).bfloat16().contiguous()
+    check(lib().dh_debug_upsample2_add_bf16(td.data_ptr(), dxd.data_ptr(), B, Ho, Ho, Hi, Hi, C, None), "upsample2")
+    want = dx0.clone()
+    want[:, ::2, ::2, :] = _bf(want[:, ::2, ::2, :] + t)
+    assert torch.equal(dxd.float().cpu(), want)
+    # odd input size: Hi = 2 Ho - 1
+    Hi2 = 2 * Ho - 1
+    dx1 = _bf(torch.randn(B, Hi2, Hi2, C, generator=g))
+    dxd = dx1.to(dev).bfloat16().contiguous()
+    check(lib().dh_debug_upsample2_add_bf16(td.data_ptr(), dxd.data_ptr(), B, Ho, Ho, Hi2, Hi2, C, None), "upsample2")
+    want = dx1.clone()
+    want[:, ::2, ::2, :] = _bf(want[:, ::2, ::2, :] + t)
+    assert torch.equal(dxd.float().cpu(), want)
+    # average pool + fc backward
+    B, HW, C, K = 5, 49, 2048, 5
+    dl = torch.randn(B, K, generator=g) * 0.1
+    w = torch.randn(K, C, generator=g) * 0.05
+    dx = torch.empty(B, HW, C, dtype=torch.bfloat16, device=dev)
+    dld, wd = dl.to(dev), w.to(dev)
+    check(lib().dh_debug_avgpool_fc_dgrad2(dld.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, HW, C, K, None), "avgpool fc")
+    want = (dl.double() @ w.double() / HW)[:, None, :].expand(B, HW, C)
+    got = dx.float().cpu().double()
+    assert float((got - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
