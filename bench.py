@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=10,
+    ap.add_argument("--train-steps", type=int, default=60,
                     help="extra legs: time this many fused training steps (configs[1] f32 ResNet-18, configs[4] bf16 ResNet-50); 0 = skip")
     ap.add_argument("--f32-steps", type=int, default=2, help="extra leg: whole slides in float32 (0 = skip)")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline measurement only (profiling runs)")
@@ -113,6 +113,52 @@ def cpu_baseline(args, budget_s: float) -> dict:
 
 
 ADAM_BYTES_R18 = 7 * 11_179_077 * 4   # read p, g, m, v + write p, m, v (~313 MB per step)
+HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md (6 290 GB/s measured for a float4 copy)
+
+
+def train_hbm_bytes(arch: str, dtype: str, B: int, P: int) -> dict:
+    """Algorithmic HBM bytes of one training step as the engines structure it (every tensor counted once per kernel
+    that reads or writes it; operand re-reads inside a kernel, weights and the slab buffers of the weight gradients are
+    left out).  Per conv + BN: forward  conv (in, Z) | statistics (Z; none for a bf16 1x1 conv: GEMM epilogue) | apply
+    (Z [, identity], Y);  backward  BN reduce (Z, dY [, Y]) | BN apply (Z, dY [, Y], dZ [, masked copy]) | wgrad (X, dZ)
+    | dgrad (dZ, dX [, identity gradient]).  Plus max-pool, Adam (7 x 4 B per parameter) and the weight re-packing."""
+    e = 4 if dtype == "f32" else 2
+    H1 = (P + 6 - 7) // 2 + 1
+    H2 = (H1 + 2 - 3) // 2 + 1
+    convs = [(3, 64, 7, P, H1, False, False)]          # (cin, cout, ks, Hi, Ho, joins an identity, has downsample input)
+    h, cin = H2, 64
+    if arch == "resnet18":
+        for s, c in enumerate((64, 128, 256, 512)):
+            for blk in range(2):
+                st = 2 if (blk == 0 and s > 0) else 1
+                ho = (h + 2 - 3) // st + 1
+                convs += [(cin, c, 3, h, ho, False, False), (c, c, 3, ho, ho, True, False)]
+                if st != 1 or cin != c:
+                    convs.append((cin, c, 1, h, ho, False, True))
+                h, cin = ho, c
+        n_params = 11_179_077
+    else:
+        for s, (w, nb) in enumerate(((64, 3), (128, 4), (256, 6), (512, 3))):
+            for blk in range(nb):
+                st = 2 if (blk == 0 and s > 0) else 1
+                ho = (h + 2 - 3) // st + 1
+                convs += [(cin, w, 1, h, h, False, False), (w, w, 3, h, ho, False, False), (w, 4 * w, 1, ho, ho, True, False)]
+                if st != 1 or cin != 4 * w:
+                    convs.append((cin, 4 * w, 1, h, ho, False, True))
+                h, cin = ho, 4 * w
+        n_params = 23_518_277
+    act = 0
+    for ci, co, ks, hi, ho, join, ds in convs:
+        I, O = B * hi * hi * ci * (4 if ks == 7 else e), B * ho * ho * co * e
+        fused_stats = dtype == "bf16" and ks == 1
+        fwd = I + O + (0 if fused_stats else O) + O + (O if join else 0) + O
+        bwd = (2 + (1 if join else 0)) * O + (2 + (1 if join else 0)) * O + O + (O if join else 0) + (I + O) + (O + (0 if ks == 7 else I))
+        act += fwd + bwd
+    pool = B * H1 * H1 * 64 * e * 2 + B * H2 * H2 * 64 * e * 2
+    adam = 7 * 4 * n_params
+    pack = (4 + 2 * e) * n_params
+    return {"activation_passes": act + pool, "adam": adam, "weight_packing": pack, "total": act + pool + adam + pack}
+
 
 
 def train_leg(dev, steps: int, arch: str = "resnet18", dtype: str = "f32", group=None) -> dict:
@@ -157,8 +203,12 @@ def train_leg(dev, steps: int, arch: str = "resnet18", dtype: str = "f32", group
            "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak,
                         "flop_per_sample": 3 * fwd_flop,
                         "note": "whole step (3 x forward FLOPs) over wall time, data assembly and optimizer included"}}
-    if arch == "resnet18":
-        out["roofline"]["adam_hbm_bytes_per_step"] = ADAM_BYTES_R18
+    hb = train_hbm_bytes(arch, dtype, B, P)
+    gbs = world * hb["total"] * steps / dt / 1e9
+    out["roofline"].update({"hbm_bytes_per_step": hb["total"], "hbm_bytes_breakdown": hb, "hbm_achieved_gbs": gbs,
+                            "hbm_peak_gbs": HBM_PEAK_GBS * world, "hbm_frac": gbs / (HBM_PEAK_GBS * world),
+                            "hbm_note": "algorithmic bytes of the engine's passes (train_hbm_bytes) over wall time: the BN / pooling / "
+                                        "Adam passes are HBM-bound, the convolutions MFMA-bound; both fractions describe the same step"})
     if world > 1:
         out["config"]["parallelism"] = f"dp{world}: bucketed (~25 MB) all-reduce overlapped with backward"
         out["buckets"] = [c for _, _, c in getattr(getattr(model, "_engine", model), "overlap_log", [])]
@@ -214,10 +264,12 @@ def cpu_sampler_baseline(args, budget_s: float) -> dict:
             "sample": f"{n} tiles ({n // 256} passes over a {side}x{side} closed-form slide), patch {args.patch}, batch {args.batch}, one process, {dt:.1f} s"}
 
 
-def cpu_train_baseline(steps: int) -> dict:
-    """torch-CPU eager ResNet-18 restatement, CrossEntropyLoss, Adam(lr=1e-4), all cores."""
-    from oracle import resnet18 as oracle_net
+def cpu_train_baseline(steps: int, arch: str = "resnet18") -> dict:
+    """torch-CPU eager ResNet-18 / ResNet-50 restatement, CrossEntropyLoss, Adam(lr=1e-4), all cores."""
+    from oracle import resnet18 as o18
+    from oracle import resnet50 as o50
 
+    oracle_net = o18 if arch == "resnet18" else o50
     threads = host_cores()
     torch.set_num_threads(threads)
     net = oracle_net.seeded_model(0, 5).train()
@@ -225,13 +277,13 @@ def cpu_train_baseline(steps: int) -> dict:
     g = torch.Generator().manual_seed(0)
     x = torch.rand(64, 3, 224, 224, generator=g)
     y = torch.randint(0, 5, (64,), generator=g)
-    oracle_net.train_step(net, opt, x, y)
+    o18.train_step(net, opt, x, y)
     t0 = time.perf_counter()
     for _ in range(steps):
-        oracle_net.train_step(net, opt, x, y)
+        o18.train_step(net, opt, x, y)
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps of batch 64 x 224^2, torch-CPU fp32 ResNet-18 eager + Adam, {threads} threads, {dt:.1f} s"}
+            "sample": f"{steps} steps of batch 64 x 224^2, torch-CPU fp32 {arch} eager + Adam, {threads} threads, {dt:.1f} s"}
 
 
 def main():
@@ -319,8 +371,8 @@ def main():
         achieved = (k_flops_v / (k_ms_v * 1e-3)) / 1e12 if k_ms_v > 0 else 0.0
         flop_tile = FLOP_PER_TILE_256 * (args.patch / 256.0) ** 2
         traffic = None   # HBM bytes per launch of the dominant kernel: from the committed PMC passes (rocprofv3
-        pmc = next((q for q in (REPO / "profiles" / "r02_pmc_dominant_kernel.json", REPO / "profiles" / "r01_pmc_dominant_kernel.json")
-                    if q.exists()), REPO / "none")                  # cannot run inside the timed process)
+        pmc = next((q for q in (REPO / "profiles" / "r03_pmc_dominant_kernel.json", REPO / "profiles" / "r02_pmc_dominant_kernel.json",
+                                REPO / "profiles" / "r01_pmc_dominant_kernel.json") if q.exists()), REPO / "none")   # cannot run inside the timed process)
         if pmc.exists() and args.dtype == "bf16" and args.patch == 256:
             doc = json.loads(pmc.read_text())
             if doc.get("micro_batch") == args.micro_batch:
@@ -343,6 +395,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<{args.dtype}, stride 1, NT=2, 8 waves> (layers 1-3, 10 of 20 convs; two instantiations: layer 1 keeps its weights resident in LDS)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
+                         "traffic_source": (f"profiles/{pmc.name} (two separate rocprofv3 --pmc passes of this command, FETCH_SIZE x 2 + "
+                                            "WRITE_SIZE, per launch; not measured in this run)") if traffic is not None else None,
                          "launches_timed": k_n_v,
                          "avg_launch_us": 1e3 * k_ms_v / max(1, k_n_v),
                          "flops_per_launch": k_flops_v / max(1, k_n_v)},
@@ -377,7 +431,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             if not args.no_extra_legs:
                 out["cpu_baselines"] = {"sampler_generator_torch": cpu_sampler_baseline(args, 4.0),
-                                        "train_step_resnet18_f32": cpu_train_baseline(2)}
+                                        "train_step_resnet18_f32": cpu_train_baseline(2),
+                                        "train_step_resnet50_f32": cpu_train_baseline(2, "resnet50")}
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
