@@ -706,7 +706,7 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
   constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
   const std::vector<int> key = {current_device(), STRIDE, NT, WAVES, MT, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi,
                                 p.Cin, p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes, p.Ho, p.Wo, p.Cout, p.out_px,
-                                p.out_cb};
+                                p.out_cb, (int)(p.o_img & 0x7FFFFFFF), (int)(p.o_img >> 31), p.o_row, p.o_px, p.o_base};
   std::lock_guard<std::mutex> lk(g_host_mu);
   auto it = g_conv3_tables.find(key);
   if (it != g_conv3_tables.end()) { *out = it->second; return DH_OK; }
@@ -739,7 +739,7 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
       const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
       const int ty = rem / p.TW, tx = rem % p.TW;
       pix[(size_t)tid * NT + nt] = {ty, tx, img};
-      row[nt] = img * p.Ho * p.Wo * p.Cout + (ty * p.Wo + tx) * p.out_px;   // output element offset relative to the tile's origin
+      row[nt] = (int)(img * p.o_img + (int64_t)ty * p.o_row + (int64_t)tx * p.o_px);   // output element offset relative to the tile's origin
       row[NT + nt] = (img * p.HR + ty * STRIDE) * p.HP + tx;
     }
     // window DMA: instruction i = wave + WAVES*j fills LDS pixels 16i..16i+15; lane l fills LDS slot (l&3)
@@ -810,7 +810,7 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
       const int mrow = mask_row_of(img0, oy0, ox0);
       DH_REQUIRE(mrow < 4096, "conv3x3: too many distinct tile positions for the mask table");
       const int64_t win_off = (int64_t)img0 * p.Hi * p.Wi * p.Cin * ESZ + (int64_t)((oy0 * STRIDE) * p.Wi + ox0 * STRIDE) * p.in_px_bytes;
-      const int64_t out_off = (int64_t)img0 * p.Ho * p.Wo * p.Cout + (int64_t)(oy0 * p.Wo + ox0) * p.out_px + (int64_t)cb * p.out_cb;
+      const int64_t out_off = (int64_t)img0 * p.o_img + (int64_t)oy0 * p.o_row + (int64_t)ox0 * p.o_px + p.o_base + (int64_t)cb * p.out_cb;
       DH_REQUIRE(win_off < ((int64_t)1 << 32) && out_off < ((int64_t)1 << 32), "conv3x3: tensor larger than 4 Gi elements / bytes");
       tile[(size_t)it * grid + w] = make_int4(cb | (valid << 16) | (mrow << 20), (int)(uint32_t)win_off, (int)(uint32_t)out_off, 0);
     }
@@ -827,7 +827,7 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
   return DH_OK;
 }
 
-template <typename T, int STRIDE, int NT, int WAVES, bool DS = false, int MT = 2, bool WRES = false>
+template <typename T, int STRIDE, int NT, int WAVES, bool DS = false, int MT = 2, bool WRES = false, int CLS = -1>
 int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   const int win_bytes = p.IMGS * p.HR * p.HP * CHUNK_BYTES;
   const size_t wslab = (size_t)(9 + (DS ? 1 : 0)) * SLAB_TAP, win_alloc = (win_bytes + 1023) & ~1023;
@@ -850,6 +850,12 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   int rc = conv3_tables<STRIDE, NT, WAVES, (int)sizeof(T), MT>(p, L.cout / 64, groups, &tb);
   if (rc) return rc;
   p.lane_tab = tb.lane; p.tile_tab = tb.tile; p.mask_tab = tb.mask;
+  if constexpr (CLS >= 0) {   // parity class of a stride-2 data gradient: no cycle-stamped twin
+    if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES, CLS>), 160 * 1024))) return rc;
+    hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES, CLS>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+    DH_LAUNCH_CHECK();
+    return DH_OK;
+  }
   if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES>), 160 * 1024)) ||
       (rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>), 160 * 1024))) return rc;
   if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
@@ -858,11 +864,15 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   return DH_OK;
 }
 
-template <typename T, int STRIDE>
+// CLS >= 0: parity class (CLS >> 1, CLS & 1) of a stride-2 data gradient -- `in` = dZ [B][Hi][Wi][L.cin], Ho x Wo = the class's
+// rows x columns, out = the FULL-SIZE dX [B][full_h][full_w][L.cout] (NHWC), of which the class owns pixels (2 i + py, 2 j + px).
+template <typename T, int STRIDE, int CLS = -1>
 int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* out, int B, int Hi, int Wi,
                    bool relu, hipStream_t st, int Ho, int Wo, const ConvLayer* ds = nullptr, void* ds_out = nullptr,
-                   bool blocked = false) {
+                   bool blocked = false, int full_h = 0, int full_w = 0) {
   Conv3Params p;
+  static_assert(CLS < 0 || STRIDE == 1, "parity classes run on the stride-1 kernel");
+  DH_REQUIRE(CLS < 0 || (!blocked && !ds && full_h > 0 && full_w > 0), "conv3x3: a parity class needs the NHWC layout and the size of dX");
   DH_REQUIRE(!blocked || sizeof(T) == 2, "conv3x3: the channel-blocked layout is the bf16 inference layout");
   if (blocked) {   // [image][C/32][H][W][32]
     p.in_px_bytes = CHUNK_BYTES; p.in_chunk_bytes = Hi * Wi * CHUNK_BYTES;
@@ -870,6 +880,12 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
   } else {         // NHWC
     p.in_px_bytes = L.cin * (int)sizeof(T); p.in_chunk_bytes = CHUNK_BYTES;
     p.out_px = L.cout; p.out_mt = 32; p.out_cb = 64;
+  }
+  if (CLS >= 0) {
+    p.o_img = (int64_t)full_h * full_w * L.cout; p.o_row = 2 * full_w * L.cout; p.o_px = 2 * L.cout;
+    p.o_base = ((CLS >> 1) * full_w + (CLS & 1)) * L.cout;
+  } else {
+    p.o_img = (int64_t)Ho * Wo * L.cout; p.o_row = Wo * p.out_px; p.o_px = p.out_px; p.o_base = 0;
   }
   p.ds_w = ds ? ds->w_dev : nullptr; p.ds_scale = ds ? ds->scale_dev : nullptr;
   p.ds_shift = ds ? ds->shift_dev : nullptr; p.ds_out = ds_out;
@@ -898,7 +914,7 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     return DH_OK;
   };
   int rc;
-  if (STRIDE == 1) {
+  if constexpr (STRIDE == 1) {
     p.HPH = 0;
     // 512-pixel tiles (NT = 2) when that still gives every CU a tile; small batches of small maps (training at
     // batch 64: 14x14 and 7x7) drop to 256- and 128-pixel tiles instead of leaving half the chip idle
@@ -922,10 +938,14 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     }
     p.HR = p.TH + 2; p.HC = p.TW + 2;
     p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
-    if ((rc = maybe_sample(variant == 0))) return rc;
+    if ((rc = maybe_sample(variant == 0 && CLS < 0))) return rc;
     // weights resident in LDS when the layer has one cout block and its slabs fit beside the window ring (bf16 64 -> 64)
     const size_t wres_lds = (size_t)L.cin * sizeof(T) / CHUNK_BYTES * 9 * SLAB_TAP + 2 * (((size_t)p.IMGS * p.HR * p.HP * CHUNK_BYTES + 1023) & ~(size_t)1023) + 1024;
-    if (variant == 0 && sizeof(T) == 2 && wres_lds <= 160 * 1024)
+    if constexpr (CLS >= 0)
+      rc = variant == 0 ? launch_conv3x3_cfg<T, 1, 2, 8, false, 2, false, CLS>(p, L, st)
+         : variant == 1 ? launch_conv3x3_cfg<T, 1, 1, 8, false, 2, false, CLS>(p, L, st)
+                        : launch_conv3x3_cfg<T, 1, 1, 8, false, 1, false, CLS>(p, L, st);
+    else if (variant == 0 && sizeof(T) == 2 && wres_lds <= 160 * 1024)
       rc = launch_conv3x3_cfg<T, 1, 2, 8, false, 2, true>(p, L, st);
     else
     rc = variant == 0 ? launch_conv3x3_cfg<T, 1, 2, 8>(p, L, st)
@@ -948,6 +968,24 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     g_prof.used += 2;
     g_prof.flops += 2.0 * B * Ho * Wo * (double)L.cout * 9 * L.cin;
   }
+  return DH_OK;
+}
+
+// Data gradient of a 3x3 / stride-2 / pad-1 convolution WITHOUT the zero-upsampled copy of dZ: four stride-1 launches, one per
+// parity class of the dX pixel (1, 2, 2 and 4 taps of the flipped + transposed operator `L.w_dev`; conv3x3.inc, CLS).  dz is
+// [B][Ho][Wo][L.cin], dx (and res, the gradient joining from another branch, may be null) [B][Hi][Wi][L.cout], NHWC.
+// (The classes write disjoint pixels and each fills at most half the chip at batch 64; running them on four streams, forked and
+// joined by events, was measured SLOWER: float32 ResNet-18 step 9.64 -> 10.63 ms -- six cross-stream dependencies per convolution
+// cost more than the idle CUs.  One stream.)
+template <typename T>
+int launch_dgrad_s2(const ConvLayer& L, const void* dz, const void* res, void* dx, int B, int Ho, int Wo, int Hi, int Wi, hipStream_t st) {
+  DH_REQUIRE(Ho == (Hi + 2 - 3) / 2 + 1 && Wo == (Wi + 2 - 3) / 2 + 1, "dgrad s2: %dx%d is not the stride-2 output of %dx%d", Ho, Wo, Hi, Wi);
+  int rc;
+  const int re = (Hi + 1) / 2, ro = Hi / 2, ce = (Wi + 1) / 2, co = Wi / 2;   // rows / columns of dX with even / odd index
+  if (ro > 0 && co > 0 && (rc = launch_conv3x3<T, 1, 3>(L, dz, res, dx, B, Ho, Wo, false, st, ro, co, nullptr, nullptr, false, Hi, Wi))) return rc;
+  if (re > 0 && co > 0 && (rc = launch_conv3x3<T, 1, 1>(L, dz, res, dx, B, Ho, Wo, false, st, re, co, nullptr, nullptr, false, Hi, Wi))) return rc;
+  if (ro > 0 && ce > 0 && (rc = launch_conv3x3<T, 1, 2>(L, dz, res, dx, B, Ho, Wo, false, st, ro, ce, nullptr, nullptr, false, Hi, Wi))) return rc;
+  if (re > 0 && ce > 0 && (rc = launch_conv3x3<T, 1, 0>(L, dz, res, dx, B, Ho, Wo, false, st, re, ce, nullptr, nullptr, false, Hi, Wi))) return rc;
   return DH_OK;
 }
 
