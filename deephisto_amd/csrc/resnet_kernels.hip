@@ -922,20 +922,29 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
       return ((B + imgs - 1) / imgs) * ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw) * (L.cout / 64);
     };
     int variant;  // 0: NT=2 MT=2 (512 px)   1: NT=1 MT=2 (256 px)   2: NT=1 MT=1 (128 px)
+    // candidates from the largest tile down; the first that gives every CU a tile wins, else the smallest (round 3: a launch
+    // with few pixels -- a parity class of a stride-2 data gradient at batch 64 -- used to run 512-pixel tiles on half the chip)
+    struct Cand { int th, tw, imgs, hp, variant; };
+    Cand cands[4];
+    int nc = 0;
     if (Wo > 16) {
       // 16x32 or 8x64 output pixels, whichever wastes fewer tile slots (56x56: 77 % vs 88 % useful)
       const int slots_a = ((Ho + 15) / 16) * ((Wo + 31) / 32), slots_b = ((Ho + 7) / 8) * ((Wo + 63) / 64);
-      if (slots_b < slots_a) { p.TH = 8; p.TW = 64; p.IMGS = 1; p.HP = 66; }
-      else { p.TH = 16; p.TW = 32; p.IMGS = 1; p.HP = 34; }
-      variant = 0;
-    }
-    else if (Wo > 8) {
-      if (ntiles_of(16, 16, 2) >= 256) { p.TH = 16; p.TW = 16; p.IMGS = 2; p.HP = 18; variant = 0; }
-      else { p.TH = 16; p.TW = 16; p.IMGS = 1; p.HP = 18; variant = 1; }
+      if (slots_b < slots_a) cands[nc++] = {8, 64, 1, 66, 0};
+      else cands[nc++] = {16, 32, 1, 34, 0};
+      cands[nc++] = {16, 16, 1, 18, 1};
+    } else if (Wo > 8) {
+      cands[nc++] = {16, 16, 2, 18, 0};
+      cands[nc++] = {16, 16, 1, 18, 1};
+      cands[nc++] = {8, 8, 2, 12, 2};
     } else {
-      if (ntiles_of(8, 8, 4) >= 256) { p.TH = 8; p.TW = 8; p.IMGS = 4; p.HP = 12; variant = 1; }   // pitch 12: see lane_pos
-      else { p.TH = 8; p.TW = 8; p.IMGS = 2; p.HP = 12; variant = 2; }
+      cands[nc++] = {8, 8, 4, 12, 1};   // pitch 12: see lane_pos
+      cands[nc++] = {8, 8, 2, 12, 2};
     }
+    int pick = nc - 1;
+    for (int i = 0; i < nc; ++i)
+      if (ntiles_of(cands[i].th, cands[i].tw, cands[i].imgs) >= 256) { pick = i; break; }
+    p.TH = cands[pick].th; p.TW = cands[pick].tw; p.IMGS = cands[pick].imgs; p.HP = cands[pick].hp; variant = cands[pick].variant;
     p.HR = p.TH + 2; p.HC = p.TW + 2;
     p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
     if ((rc = maybe_sample(variant == 0 && CLS < 0))) return rc;
