@@ -942,8 +942,9 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
       cands[nc++] = {8, 8, 2, 12, 2};
     }
     int pick = nc - 1;
+    static const int min_tiles = getenv("DH_CONV_MIN_TILES") ? atoi(getenv("DH_CONV_MIN_TILES")) : 256;
     for (int i = 0; i < nc; ++i)
-      if (ntiles_of(cands[i].th, cands[i].tw, cands[i].imgs) >= 256) { pick = i; break; }
+      if (ntiles_of(cands[i].th, cands[i].tw, cands[i].imgs) >= min_tiles) { pick = i; break; }
     p.TH = cands[pick].th; p.TW = cands[pick].tw; p.IMGS = cands[pick].imgs; p.HP = cands[pick].hp; variant = cands[pick].variant;
     p.HR = p.TH + 2; p.HC = p.TW + 2;
     p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;

@@ -19,12 +19,12 @@ def avg_counter(path, name):
         k = r["Kernel_Name"]
         if r["Counter_Name"] != name or "conv3x3_kernel" not in k:
             continue
-        # template args: <T, STRIDE, NT, WAVES, STAMP, DS, MT>
+        # template args: <T, STRIDE, NT, WAVES, STAMP, DS, MT, WRES, CLS>
         args = k[k.index("<") + 1:k.rindex(">")].replace(" ", "").split(",")
         # rocprofv3 garbles the first two (type, stride) in its demangling; NT=2 exists for stride 1 only and the
-        # bench runs bf16 only, so <..., NT=2, WAVES=8, STAMP=false, DS=false, MT=2, WRES> identifies the variant
-        # (the trailing WRES flag distinguishes the layer-1 instantiation: both belong to the variant)
-        if args[-6:-1] == ["2", "8", "false", "false", "2"]:
+        # bench runs bf16 only, so <..., NT=2, WAVES=8, STAMP=false, DS=false, MT=2, WRES, CLS=-1> identifies the variant
+        # (the WRES flag distinguishes the layer-1 instantiation: both belong to the variant)
+        if args[-7:-2] == ["2", "8", "false", "false", "2"] and args[-1] == "-1":
             vals.append(float(r["Counter_Value"]))
     return sum(vals) / len(vals), len(vals)
 

@@ -3,7 +3,7 @@
 # default bench line, rocprofv3 kernel stats of the same command, the two --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs,
 # kernel trace only), per-layer table, MFMA utilisation per layer (SQ counters), conv phase stamps, training kernel stats.
 set -e
-RND=${1:-r02}
+RND=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; P=$O/profiles_$RND; mkdir -p $P
 cd $R
@@ -23,7 +23,7 @@ rocprofv3 --output-format csv --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFM
 python3 tools/pmc_mfma_util.py $O/pmc_mfma $P/${RND}_pmc_mfma_util.json
 echo "pmc mfma done"
 python3 tools/conv_stamps.py 256 > $P/${RND}_conv_phase_stamps.txt 2>/dev/null
-for a in resnet18 resnet50; do
+for a in resnet18 resnet18bf16 resnet50; do
   rm -rf $O/prof_train_$a
   rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_train_$a -o t -- python3 tools/train_profile.py $a > $O/train_prof_$a.log 2>&1
   cp $(find $O/prof_train_$a -name 't_kernel_stats.csv' | head -1) $P/${RND}_train_${a}_kernel_stats.csv
