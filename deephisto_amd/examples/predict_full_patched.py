@@ -184,7 +184,7 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     P = sampler.patch_size
     origins = sampler.origins                      # padded, reference order
     n_unique, n_padded = sampler.n_tiles, len(origins)
-    mb = micro_batch or 1024   # tiles per kernel launch (independent of the sampler's batch size)
+    mb = micro_batch or 4096   # tiles per kernel launch (independent of the sampler's batch size; the library's maximum)
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/*_pmc_dominant_kernel.json.
 
-Tooling, not product.  Usage: pmc_summary.py <fetch_dir> <write_dir> <micro_batch> <out.json>
+Tooling, not product.  Usage: pmc_summary.py <fetch_dir> <write_dir> <micro_batch> <out.json> [tiles_per_launch]
 The dominant kernel is conv3x3_kernel<bf16, stride 1, NT=2, 8 waves> (layers 1-3 of ResNet-18 at
 256x256 tiles).  gfx950 corrections follow MI355X_MICROARCH.md (HBM / rocprofv3 section): counters
 are in KiB; FETCH_SIZE under-counts 16-B-per-lane streaming reads by 2x; WRITE_SIZE is taken as is.
@@ -38,19 +38,20 @@ def algorithmic_bytes(mb):
     return tot / 10
 
 
-def main(fetch_dir, write_dir, mb, out):
+def main(fetch_dir, write_dir, mb, out, tiles=None):
+    tiles = int(tiles) if tiles else int(mb)   # tiles actually in one launch (38 416 tiles at micro-batch 4096: 10 launches of 3 842)
     fetch, n = avg_counter(fetch_dir, "FETCH_SIZE")
     write, _ = avg_counter(write_dir, "WRITE_SIZE")
     doc = {
         "kernel": "conv3x3_kernel<bf16, stride 1, NT=2, 8 waves>",
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) -- "
                    "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --train-steps 0",
-        "micro_batch": int(mb), "launches": n,
+        "micro_batch": int(mb), "tiles_per_launch": tiles, "launches": n,
         "FETCH_SIZE_avg_KB": fetch, "WRITE_SIZE_avg_KB": write,
         "correction": "gfx950: FETCH_SIZE counts 1/2 of the bytes of 16-B-per-lane streaming reads "
                       "(MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE taken as is; units KiB",
         "traffic_bytes_per_launch": (2 * fetch + write) * 1024,
-        "algorithmic_bytes_per_launch": algorithmic_bytes(int(mb)),
+        "algorithmic_bytes_per_launch": algorithmic_bytes(tiles),
         "note": "algorithmic = input + output (+ residual on 6 of 10) + weights, no halo, averaged over the 10 "
                 "launches per forward of this variant (layer1 x4, layer2 x3, layer3 x3)",
     }
@@ -59,4 +60,4 @@ def main(fetch_dir, write_dir, mb, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

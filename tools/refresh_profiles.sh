@@ -12,11 +12,11 @@ echo "bench done"
 rm -rf $O/prof_stats $O/pmc_fetch $O/pmc_write
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats -o st -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --train-steps 0 > $O/bench_prof.json 2> $O/bench_prof.err
 cp $(find $O/prof_stats -name 'st_kernel_stats.csv' | head -1) $P/${RND}_bench_kernel_stats.csv
-python3 tools/trace_summary.py $O/prof_stats 1024 > $P/${RND}_bench_per_layer.txt
+python3 tools/trace_summary.py $O/prof_stats 3842 > $P/${RND}_bench_per_layer.txt
 echo "stats done"
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-legs --train-steps 0 > $O/pmc_f.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-legs --train-steps 0 > $O/pmc_w.log 2>&1
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 1024 $P/${RND}_pmc_dominant_kernel.json > /dev/null
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 4096 $P/${RND}_pmc_dominant_kernel.json 3842 > /dev/null
 echo "pmc traffic done"
 rm -rf $O/pmc_mfma
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -d $O/pmc_mfma -o c -- python3 tools/fwd_once.py 256 3 > $O/pmc_mfma.log 2>&1
