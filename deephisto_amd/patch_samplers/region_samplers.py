@@ -133,13 +133,16 @@ class RectRegionRndSampler:
         """Fast path of the training loop: [B,3,P,P] batches with train.py:71-81's
         permute + batch-level random flips fused into the gather kernel."""
         dev = self.slide.device
+        up = getattr(self, "_uploader", None)
+        if up is None:
+            up = self._uploader = tiles.PinnedUploader(dev)   # origins / labels through pinned staging: the host never waits for the GPU
         for _ in range(n_batches):
             yx, lab = self.sample_origins(batch_size)
             fh = bool(flips and self._rng.random() < 0.5)
             fv = bool(flips and self._rng.random() < 0.5)
-            o_dev = torch.from_numpy(yx).to(dev)
+            o_dev = up.upload(yx)
             x = tiles.gather_tiles_aug(self.slide, o_dev, self.patch_size, DH_LAYOUT_NCHW, dtype, fh, fv)
-            yield x, torch.from_numpy(lab).to(dev), tiles.tile_coords(o_dev)
+            yield x, up.upload(lab), tiles.tile_coords(o_dev)
 
 
 def synthetic_regions(h: int, w: int, n_classes: int = 5, per_class: int = 6, min_side: int = 300,
@@ -431,18 +434,21 @@ class AnnoRegionRndSampler:
         dev, ps = self._bank.device, self.patch_size
         arr = np.array(recs, dtype=np.int64).reshape(-1, 4)
         out = None
+        up = getattr(self, "_uploader", None)
+        if up is None:
+            up = self._uploader = tiles.PinnedUploader(dev, depth=8)   # non-blocking uploads (tiles.PinnedUploader)
         for j in np.unique(arr[:, 0]):
             sel = np.nonzero(arr[:, 0] == j)[0]
-            o_dev = torch.from_numpy(arr[sel, 1:3].astype(np.int32)).to(dev)
+            o_dev = up.upload(arr[sel, 1:3].astype(np.int32))
             part = tiles.gather_tiles_aug(self._bank.slide(int(j)), o_dev, ps, layout, dtype, flip_h, flip_v)
             if len(sel) == len(arr):
                 out = part
             else:
                 if out is None:
                     out = torch.empty((len(arr),) + tuple(part.shape[1:]), dtype=part.dtype, device=dev)
-                out[torch.from_numpy(sel).to(dev)] = part
-        labels = torch.from_numpy(arr[:, 3].copy()).to(dev)
-        coords = torch.from_numpy(arr[:, 1:3].astype(np.float32)).to(dev)
+                out[up.upload(sel.astype(np.int64))] = part
+        labels = up.upload(arr[:, 3].copy())
+        coords = up.upload(arr[:, 1:3].astype(np.float32))
         return out, labels, coords
 
     def torch_generator(self, batch_size: int, n_batches: int, batches_per_worker: int = 2,

@@ -94,6 +94,40 @@ def gather_tiles_aug(slide: torch.Tensor, origins_dev: torch.Tensor, patch: int,
     return out
 
 
+class PinnedUploader:
+    """Host -> device copies of small per-batch arrays (tile origins, labels) that do not stall the host.
+
+    `torch.from_numpy(a).to(dev)` from pageable memory synchronises the stream: the host cannot prepare batch i+1 while the
+    GPU runs step i, and every step starts with an idle GPU.  Here the array is written into one of `depth` pinned staging
+    buffers and copied with `non_blocking=True`; an event per slot makes sure a slot is not overwritten before its last
+    copy has completed (normally long since)."""
+
+    def __init__(self, device, depth: int = 4):
+        self.device, self.depth = torch.device(device), depth
+        self._slots: dict = {}
+        self._next: dict = {}
+
+    def upload(self, arr: "np.ndarray") -> torch.Tensor:
+        import numpy as np
+
+        arr = np.ascontiguousarray(arr)
+        key = (arr.dtype.str, arr.shape)
+        if key not in self._slots:
+            self._slots[key] = [[torch.from_numpy(np.empty_like(arr)).pin_memory(), None] for _ in range(self.depth)]
+            self._next[key] = 0
+        k = self._next[key]
+        self._next[key] = (k + 1) % self.depth
+        slot = self._slots[key][k]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0].numpy()[...] = arr
+        out = slot[0].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        slot[1] = ev
+        return out
+
+
 def gather_tiles_raw(slide: torch.Tensor, origins_dev: torch.Tensor, patch: int) -> torch.Tensor:
     """float32[n, P, P, 3] of the raw 0..255 pixel values (FullImageRndSampler.generator_torch)."""
     _require_cuda(slide, "slide")
