@@ -235,6 +235,12 @@ int dh_debug_gemm1x1_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const ui
 int dh_debug_gemm1x1_fused_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const uint16_t* res_dev, const uint16_t* mask_dev,
                                 uint16_t* out_dev, float* mean_dev, float* invstd_dev, int64_t M, int32_t N, int32_t K, int32_t stride,
                                 int32_t Ho, int32_t Wo, int32_t Hi, int32_t Wi, int32_t repeat, void* stream);
+/* dh_debug_gemm1x1_bwdsums_bf16: the dgrad GEMM whose output is the dY of a batch norm, with that BN's backward sums fused into the
+ * epilogue: sums_dev[0..N) = sum g, sums_dev[N..2N) = sum g xhat (relu_mode 0: g = out as stored; 2: the BN's ReLU recomputed from z). */
+int dh_debug_gemm1x1_bwdsums_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const uint16_t* res_dev, const uint16_t* mask_dev,
+                                  uint16_t* out_dev, const uint16_t* z_dev, const float* mean_dev, const float* invstd_dev,
+                                  const float* scale_dev, const float* shift_dev, int32_t relu_mode, float* sums_dev, int64_t M, int32_t N,
+                                  int32_t K, void* stream);
 /* dh_debug_bn2_bf16: the bf16 engine's batch-norm kernels on caller data ([rows][C] channels-last, bf16 bits): forward with batch
  * statistics (y, saved mean / invstd), and, when dy_dev is given, backward (dz, dgamma, dbeta; relu_mode 0 none, 1 mask from y,
  * 2 mask recomputed from z; g_out_dev: the masked gradient, may be null). */

@@ -381,3 +381,37 @@ def test_upsample2_add_and_avgpool_fc_dgrad_bf16(dev):
     want = (dl.double() @ w.double() / HW)[:, None, :].expand(B, HW, C)
     got = dx.float().cpu().double()
     assert float((got - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(777, 64, 256, 2), (3136, 256, 64, 0), (12544, 128, 512, 2), (50176 + 3, 256, 64, 0)])
+def test_gemm1x1_fused_bn_backward_sums(dev, M, N, K, mode):
+    """The dgrad GEMM's epilogue leaves the sums of the following BN backward (sum g, sum g xhat): against float64 over the kernel's
+    own (bf16) output and the same z / mean / invstd: relative 1e-5.  mode 2: g = out where fma(z, scale, shift) > 0 (float32, as
+    the apply kernels compute it); mode 0: g = out as stored (here masked by a ReLU-output tensor, the pre-masked join gradient)."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(M + N + K + mode)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev).bfloat16().contiguous()
+    w = _bf(torch.randn(N, K, generator=g) * (1.0 / K) ** 0.5).to(dev).bfloat16().contiguous()
+    res = _bf(torch.randn(M, N, generator=g)).to(dev).bfloat16().contiguous() if mode == 0 else None
+    msk = torch.relu(torch.randn(M, N, generator=g)).to(dev).bfloat16().contiguous() if mode == 0 else None
+    z = _bf(torch.randn(M, N, generator=g) * 1.5 + 0.3).to(dev).bfloat16().contiguous()
+    mean = z.float().mean(0).contiguous()
+    invstd = (1.0 / torch.sqrt(z.float().var(0, unbiased=False) + 1e-5)).contiguous()
+    gamma = (torch.rand(N, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(N, generator=g) * 0.3).to(dev)
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    sums = torch.empty(2 * N, dtype=torch.float32, device=dev)
+    check(lib().dh_debug_gemm1x1_bwdsums_bf16(a.data_ptr(), w.data_ptr(), res.data_ptr() if res is not None else None,
+                                              msk.data_ptr() if msk is not None else None, out.data_ptr(), z.data_ptr(), mean.data_ptr(),
+                                              invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mode, sums.data_ptr(), M, N, K, None), "bwd sums")
+    o = out.float()
+    if mode == 2:
+        o = o * (torch.addcmul(shift, z.float(), scale) > 0).float()      # fma(z, scale, shift) > 0 in float32
+    xhat = (z.double() - mean.double()) * invstd.double()
+    s1 = o.double().sum(0)
+    s2 = (o.double() * xhat).sum(0)
+    assert _rel(sums[:N].cpu(), s1.cpu()) <= 1e-5 and _rel(sums[N:].cpu(), s2.cpu()) <= 1e-5
+    if mode == 0:
+        assert int((out[msk.float() <= 0].view(torch.int16) != 0).sum()) == 0
