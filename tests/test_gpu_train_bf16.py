@@ -196,6 +196,50 @@ def test_bench_shape_runs_and_learns(dev):
     assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses
 
 
+def test_bench_shape_slices_against_the_emulation(dev):
+    """64 x 224^2 (the bench shape: every layer on its large-launch path, fused GEMM epilogues, side-stream weight gradients) held
+    against the bf16 emulation where that is affordable on the host: on the first 8 images of the batch
+      * conv1's output Z (per-image work: the emulation's 7x7 convolution of the same bf16 inputs): 1e-4 relative L2;
+      * layer1.0.conv1's output Z: the emulation's max-pool + 1x1 convolution applied to the ENGINE's normalised stem map of those
+        images (the batch statistics come from all 64 images, so the slice takes them from the engine): 2e-3;
+    and, on the whole batch, the fc gradients recomputed on the host from the engine's own logits and its last block output
+    (dW = dlogits^T . pooled, db = sum dlogits; float64): 1e-3 relative (pooled features are bf16 activations averaged in float32)."""
+    ref, m = _pair(dev, "resnet50", 4, 0.2)
+    g = torch.Generator().manual_seed(2)
+    B, P, S = 64, 224, 8
+    x = torch.rand(B, 3, P, P, generator=g)
+    y = torch.randint(0, 5, (B,), generator=g)
+    loss, logits = m.train_step(x.to(dev), y.to(dev), lr=1e-4)
+    grads = m.flat_gradients(dev).clone()
+    assert np.isfinite(float(loss))
+    from oracle.bf16_emulation import rb
+    # conv1 Z of the first S images
+    z1 = _act(m, "conv1", 0, (B, 64, 112, 112), dev)[:S]
+    want1 = rb(F.conv2d(rb(x[:S]), rb(ref.conv1.weight.detach()), None, 2, 3))
+    assert float((z1 - want1).norm() / want1.norm()) <= 1e-4
+    # layer1.0.conv1 Z from the engine's normalised stem map
+    y0 = _act(m, "conv1", 1, (B, 64, 112, 112), dev)[:S]
+    want2 = rb(F.conv2d(F.max_pool2d(y0, 3, 2, 1), rb(ref.layer1[0].conv1.weight.detach())))
+    z2 = _act(m, "layer1.0.conv1", 0, (B, 64, 56, 56), dev)[:S]
+    assert float((z2 - want2).norm() / want2.norm()) <= 2e-3
+    # fc gradients of the whole batch from the engine's logits and last block output
+    ylast = _act(m, "layer4.2.conv3", 1, (B, 2048, 7, 7), dev).double()
+    pooled = ylast.mean((2, 3))
+    dl = (torch.softmax(logits.cpu().double(), 1) - F.one_hot(y, 5).double()) / B
+    eng = _engine(m)
+    off = {}
+    from deephisto_amd._lib import check, lib
+    gw = torch.empty(5, 2048, dtype=torch.float32, device=dev)
+    gb = torch.empty(5, dtype=torch.float32, device=dev)
+    check(lib().dh_train2_tensor(eng.handle, b"fc.weight", 1, gw.data_ptr(), gw.numel(), 0, None), "grad fc.weight")
+    check(lib().dh_train2_tensor(eng.handle, b"fc.bias", 1, gb.data_ptr(), gb.numel(), 0, None), "grad fc.bias")
+    torch.cuda.synchronize()
+    want_w, want_b = dl.T @ pooled, dl.sum(0)
+    assert float((gw.cpu().double() - want_w).norm() / want_w.norm()) <= 1e-3
+    assert float((gb.cpu().double() - want_b).norm() / want_b.norm()) <= 1e-5
+    assert grads.numel() == m.flat_gradients(dev).numel()
+
+
 def test_bucket_layout_and_callback_order(dev):
     from deephisto_amd._lib import BUCKET_CB, check, lib
     _, m = _pair(dev, "resnet50", 2, 0.2)
