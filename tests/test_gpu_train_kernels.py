@@ -80,6 +80,9 @@ def test_stem_wgrad_kernel(dev, B, P):
 @pytest.mark.parametrize("ks,stride,cin,cout,B,H,res", [
     (3, 1, 64, 64, 2, 32, True), (3, 1, 256, 256, 3, 14, False), (3, 2, 64, 128, 2, 32, False),
     (3, 2, 256, 512, 3, 14, False), (1, 2, 64, 128, 2, 32, True), (1, 2, 256, 512, 3, 14, True),
+    # the four parity classes of the stride-2 data gradient (round 3): odd maps (classes of unequal size), a joining gradient,
+    # enough images for several tile rounds and for the 512-pixel tile variant
+    (3, 2, 64, 128, 2, 15, False), (3, 2, 128, 256, 3, 7, True), (3, 2, 64, 128, 40, 56, True), (3, 2, 64, 64, 2, 9, False),
 ])
 def test_dgrad_paths(dev, ks, stride, cin, cout, B, H, res):
     from deephisto_amd._lib import check, lib
