@@ -51,6 +51,7 @@ SIGNATURES = {
     "dh_resnet18_backward": (C.c_int, [_p, _p, _p]),
     "dh_ce_loss": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "dh_resnet18_adam_step": (C.c_int, [_p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
+    "dh_resnet18_backward_adam": (C.c_int, [_p, _p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
     "dh_resnet18_train_tensor": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _i32, _p]),
     "dh_resnet18_train_repack": (C.c_int, [_p, _p]),
     "dh_resnet18_train_flat": (C.c_int, [_p, _i32, C.POINTER(_p), C.POINTER(_i64)]),
@@ -65,11 +66,13 @@ SIGNATURES = {
     "dh_train2_forward": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p]),
     "dh_train2_backward": (C.c_int, [_p, _p, _p]),
     "dh_train2_adam_step": (C.c_int, [_p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
+    "dh_train2_backward_adam": (C.c_int, [_p, _p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
     "dh_train2_debug_act": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _p]),
     "dh_debug_gemm1x1_bf16": (C.c_int, [_p, _p, _p, _p, _i64] + [_i32] * 8 + [_p]),
     "dh_debug_gemm1x1_fused_bf16": (C.c_int, [_p] * 7 + [_i64] + [_i32] * 8 + [_p]),
     "dh_debug_gemm1x1_bwdsums_bf16": (C.c_int, [_p] * 10 + [_i32, _p, _i64, _i32, _i32, _p]),
     "dh_debug_bn2_bf16": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _i64, _i32, _p]),
+    "dh_debug_bn2_pool_bf16": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_maxpool2_bf16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_upsample2_add_bf16": (C.c_int, [_p, _p] + [_i32] * 6 + [_p]),
     "dh_debug_avgpool_fc_dgrad2": (C.c_int, [_p, _p, _p] + [_i32] * 4 + [_p]),

@@ -302,7 +302,14 @@ class ResNet18HIP(nn.Module):
                                dl.data_ptr(), st), "dh_ce_loss")
         import torch.distributed as dist
         red = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1)
+        if single and getattr(self, "fuse_optimizer", True):   # no gradient exchange: the update rides behind each block's weight gradients
+            self._adam_t = getattr(self, "_adam_t", 0) + 1
+            check(lib().dh_resnet18_backward_adam(self._handle, dl.data_ptr(), lr, betas[0], betas[1], eps, self._adam_t, st),
+                  "dh_resnet18_backward_adam")
+            self._native_ahead = True
+            return loss, logits
+        if not single:
             red = BucketReducer(self.flat_gradients(x.device), group)
             cb = BUCKET_CB(lambda bucket, off, cnt, _user: red.on_bucket(bucket, off, cnt))
             check(lib().dh_resnet18_set_buckets(self._handle, int(bucket_bytes), cb, None, None), "dh_resnet18_set_buckets")

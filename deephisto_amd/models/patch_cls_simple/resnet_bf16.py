@@ -39,6 +39,7 @@ class Train2Engine:
         self.native_ahead = False  # the library's parameters are newer than the nn.Parameters (fused train_step)
         self._cb = None
         self.overlap_log = []      # (bucket, offset, count) in launch order of the last data-parallel backward (tests)
+        self.fuse_optimizer = True  # single-rank train_step: dh_train2_backward_adam (False: backward, then adam_step; tests)
 
     # ---- handle and parameter traffic -------------------------------------------------------------------
     def _stream(self, dev):
@@ -163,6 +164,10 @@ class Train2Engine:
         loss, dl = ce_loss(logits, labels, want_grad=True)
         st = self._stream(x.device)
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if world == 1 and self.fuse_optimizer:   # no gradient exchange: the update rides behind each block's weight gradients
+            check(lib().dh_train2_backward_adam(self.handle, dl.data_ptr(), lr, betas[0], betas[1], eps, 0, st), "dh_train2_backward_adam")
+            self.native_ahead = True
+            return loss, logits
         red = self._arm_overlap(x.device, group, bucket_bytes) if world > 1 else None
         try:
             check(lib().dh_train2_backward(self.handle, dl.data_ptr(), st), "dh_train2_backward")

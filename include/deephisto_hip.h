@@ -178,6 +178,11 @@ int dh_ce_loss(const float* logits_dev, const int64_t* labels_dev, int64_t n, in
                float* loss_dev, float* dlogits_dev, void* stream);
 int dh_resnet18_adam_step(dh_resnet18* net, float lr, float beta1, float beta2, float eps,
                           int64_t step, void* stream);
+/* backward + Adam of a single-rank step in one call: each residual block's update and repack follow its weight
+ * gradients on the engine's side stream.  Bit-identical to dh_resnet18_backward + dh_resnet18_adam_step; refused
+ * while gradient buckets are armed. */
+int dh_resnet18_backward_adam(dh_resnet18* net, const float* dlogits_dev, float lr, float beta1, float beta2,
+                              float eps, int64_t step, void* stream);
 int dh_resnet18_train_tensor(dh_resnet18* net, const char* name, int32_t kind, void* ptr,
                              int64_t n_elem, int32_t to_lib, void* stream);
 int dh_resnet18_train_repack(dh_resnet18* net, void* stream);
@@ -221,6 +226,10 @@ int dh_train2_forward(dh_train2* net, const float* x_dev, int64_t n, int32_t pat
                       int32_t training, void* stream);
 int dh_train2_backward(dh_train2* net, const float* dlogits_dev, void* stream);
 int dh_train2_adam_step(dh_train2* net, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+/* backward + Adam of a single-rank step in one call: each residual block's update and bf16 repack follow its weight gradients on the
+ * engine's side stream.  Bit-identical to dh_train2_backward + dh_train2_adam_step; refused while gradient buckets are armed. */
+int dh_train2_backward_adam(dh_train2* net, const float* dlogits_dev, float lr, float beta1, float beta2, float eps, int64_t step,
+                            void* stream);
 /* test hook: float32 copy of conv `conv_name`'s raw output (what = 0) or BN/ReLU output (what = 1) of the last forward */
 int dh_train2_debug_act(dh_train2* net, const char* conv_name, int32_t what, float* out_dev, int64_t n_elem, void* stream);
 
@@ -247,6 +256,11 @@ int dh_debug_gemm1x1_bwdsums_bf16(const uint16_t* a_dev, const uint16_t* w_dev, 
 int dh_debug_bn2_bf16(const uint16_t* z_dev, const uint16_t* res_dev, const float* gamma_dev, const float* beta_dev, int32_t relu,
                       uint16_t* y_dev, float* mean_dev, float* invstd_dev, const uint16_t* dy_dev, int32_t relu_mode, uint16_t* dz_dev,
                       uint16_t* g_out_dev, float* dgamma_dev, float* dbeta_dev, int64_t rows, int32_t C, void* stream);
+/* the stem's fused tail (bf16 engine): pooled = maxpool3x3/2(relu(bn(z))) straight from z with batch statistics (+ positions, mean, invstd);
+ * with dpool_dev: dz, dgamma, dbeta with the maxpool's gradient gathered inside the BN backward passes. */
+int dh_debug_bn2_pool_bf16(const uint16_t* z_dev, const float* gamma_dev, const float* beta_dev, uint16_t* pooled_dev, uint8_t* idx_dev,
+                           float* mean_dev, float* invstd_dev, const uint16_t* dpool_dev, uint16_t* dz_dev, float* dgamma_dev,
+                           float* dbeta_dev, int32_t B, int32_t Hi, int32_t Wi, int32_t C, void* stream);
 /* The remaining HBM-bound kernels of the bf16 engine on caller data: max-pool 3x3/2 forward (+ backward when dy_dev is given),
  * the strided add of the downsample branch's gradient, and the average-pool + fc backward. */
 int dh_debug_maxpool2_bf16(const uint16_t* x_dev, uint16_t* y_dev, const uint16_t* dy_dev, uint16_t* dx_dev, int32_t B, int32_t Hi,

@@ -213,6 +213,30 @@ def test_train_step_is_bit_reproducible(dev):
         assert torch.equal(a[5][k], b[5][k]), k
 
 
+def test_fused_backward_adam_equals_backward_then_adam(dev):
+    """dh_resnet18_backward_adam (each block's Adam update + repack behind its weight gradients on the side stream) against
+    dh_resnet18_backward + dh_resnet18_adam_step: losses, logits of every step and the final state bit for bit."""
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    ref = oracle_net.seeded_model(22, 5, perturb_bn=True)
+    g = torch.Generator().manual_seed(78)
+    x = torch.rand(8, 3, 96, 96, generator=g).to(dev)
+    y = torch.randint(0, 5, (8,), generator=g).to(dev)
+    outs = []
+    for fuse in (True, False):
+        m = get_model(5, "f32")
+        m.load_state_dict(ref.state_dict())
+        m.to(dev).train()
+        m.fuse_optimizer = fuse
+        trace = [m.train_step(x, y, lr=1e-3) for _ in range(4)]
+        trace = [(float(l), lg.clone()) for l, lg in trace]
+        outs.append((trace, {k: v.clone() for k, v in m.state_dict().items()}))
+    (ta, sa), (tb, sb) = outs
+    for (la, ga), (lb, gb) in zip(ta, tb):
+        assert la == lb and torch.equal(ga, gb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 def test_ce_loss_rejects_out_of_range_label(dev):
     from deephisto_amd.models.patch_cls_simple.model import ce_loss
     logits = torch.randn(6, 5, device=dev)

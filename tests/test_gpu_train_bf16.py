@@ -183,6 +183,33 @@ def test_bf16_step_is_bit_reproducible(dev):
     assert torch.equal(a[2], b[2]), "gradient arena differs between two identical runs"
 
 
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_fused_backward_adam_equals_backward_then_adam(dev, arch):
+    """dh_train2_backward_adam (each block's Adam update + bf16 repack behind its weight gradients on the side stream) against
+    dh_train2_backward + dh_train2_adam_step: masters, moments-driven next steps and the repacked operands (seen through the
+    next forward) must be identical bit for bit over several steps."""
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(8, 3, 96, 96, generator=g).to(dev)
+    y = torch.randint(0, 5, (8,), generator=g).to(dev)
+    runs = []
+    for fuse in (True, False):
+        torch.manual_seed(3)
+        m = get_model(5, "bf16", arch=arch).to(dev).train()
+        eng = m._bf16_engine() if arch == "resnet18" else m._engine
+        eng.fuse_optimizer = fuse
+        trace = []
+        for _ in range(4):
+            loss, logits = m.train_step(x, y, lr=1e-3)
+            trace.append((float(loss), logits.clone()))
+        runs.append((trace, eng.flat(0, dev).clone()))
+        del m
+    (ta, pa), (tb, pb) = runs
+    assert torch.equal(pa, pb), "parameter arenas differ"
+    for (la, ga), (lb, gb) in zip(ta, tb):
+        assert la == lb and torch.equal(ga, gb)
+
+
 def test_bench_shape_runs_and_learns(dev):
     """64 x 224^2 (BASELINE configs[4] per-rank batch): every layer takes its large-launch path; the loss on a fixed batch
     must fall (no CPU oracle at this size: ResNet-50 forward + backward of 64 images is minutes of host time)."""

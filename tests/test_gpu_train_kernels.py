@@ -354,6 +354,61 @@ def test_maxpool2_bf16_kernels(dev, B, H, C):
     assert _rel(got, want) <= 3e-3
 
 
+@pytest.mark.parametrize("B,H,C", [(3, 112, 64), (2, 57, 64), (4, 30, 128)])
+def test_bn2_pool_fused_stem_tail_bf16(dev, B, H, C):
+    """The stem's tail of the bf16 engine in one pass each way: pooled = maxpool3x3/2(bf16(relu(bn(z)))) + first-maximum positions straight
+    from z (bn2_apply_pool_kernel), and dz / dgamma / dbeta with the maxpool's gradient gathered inside the BN backward passes
+    (bn2_pool_bwd_reduce / _apply).  Forward against float64: pooled values within one bf16 ulp, every recorded position holds its window's
+    maximum (within that ulp).  Backward against float64 autograd of sum(relu(bn(z)) * dY), dY = the pooled gradient scattered to the
+    recorded positions: dz within 2 bf16 ulp, dgamma / dbeta 1e-5.  Two runs: equal bits."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B * H + C + 5)
+    z = _bf(torch.randn(B, H, H, C, generator=g) * (torch.rand(C, generator=g) + 0.5) + torch.randn(C, generator=g) * 0.5)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    Hp = (H + 2 - 3) // 2 + 1
+    dpool = _bf(torch.randn(B, Hp, Hp, C, generator=g) * 1e-3)
+    z64 = z.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mu, var = z64.mean((0, 1, 2)), z64.var((0, 1, 2), unbiased=False)
+    y64 = torch.relu((z64 - mu) / torch.sqrt(var + 1e-5) * g64 + b64)                     # [B, H, H, C]
+    p64 = F.max_pool2d(y64.detach().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    zd, gd, bd, dpd = z.to(dev).bfloat16().contiguous(), gamma.to(dev), beta.to(dev), dpool.to(dev).bfloat16().contiguous()
+    outs = []
+    for _ in range(2):
+        pooled = torch.empty(B, Hp, Hp, C, dtype=torch.bfloat16, device=dev)
+        idx = torch.empty(B, Hp, Hp, C, dtype=torch.uint8, device=dev)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd, dgam, dbet = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+        dz = torch.empty(B, H, H, C, dtype=torch.bfloat16, device=dev)
+        check(lib().dh_debug_bn2_pool_bf16(zd.data_ptr(), gd.data_ptr(), bd.data_ptr(), pooled.data_ptr(), idx.data_ptr(), mean.data_ptr(),
+                                           invstd.data_ptr(), dpd.data_ptr(), dz.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), B, H, H, C, None),
+              "bn2 pool")
+        outs.append((pooled, idx, mean, invstd, dz, dgam, dbet))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    pooled, idx, mean, invstd, dz, dgam, dbet = outs[0]
+    assert float((mean.cpu().double() - mu.detach()).abs().max()) <= 1e-6 * float(z.abs().max())
+    assert float((invstd.cpu().double() * torch.sqrt(var.detach() + 1e-5) - 1).abs().max()) <= 1e-6
+    ulp = 2.0 ** -8 * float(p64.abs().max()) + 1e-6
+    assert float((pooled.float().cpu().double() - p64).abs().max()) <= ulp
+    # recorded positions: inside the map, and the value there is the window's maximum
+    ii = idx.cpu().long()
+    bb, oy, ox, cc = torch.meshgrid(torch.arange(B), torch.arange(Hp), torch.arange(Hp), torch.arange(C), indexing="ij")
+    iy, ix = 2 * oy + ii // 3 - 1, 2 * ox + ii % 3 - 1
+    assert int(ii.max()) <= 8 and bool(((iy >= 0) & (iy < H) & (ix >= 0) & (ix < H)).all())
+    at = y64.detach()[bb, iy, ix, cc]
+    assert float((at - p64).abs().max()) <= ulp
+    # backward: the pooled gradient scattered to those positions, then autograd through relu(bn(z))
+    dY = torch.zeros(B, H, H, C, dtype=torch.float64)
+    dY.index_put_((bb.reshape(-1), iy.reshape(-1), ix.reshape(-1), cc.reshape(-1)), dpool.double().reshape(-1), accumulate=True)
+    (y64 * dY).sum().backward()
+    assert _rel(dgam.cpu(), g64.grad) <= 1e-5 and _rel(dbet.cpu(), b64.grad) <= 1e-5
+    got, want = dz.float().cpu().double(), z64.grad
+    assert float((got - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+    assert _rel(got, want) <= 3e-3
+
+
 def test_upsample2_add_and_avgpool_fc_dgrad_bf16(dev):
     from deephisto_amd._lib import check, lib
     g = torch.Generator().manual_seed(77)

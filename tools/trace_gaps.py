@@ -11,10 +11,10 @@ f = p if p.is_file() else next(p.rglob("*kernel_trace.csv"))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a step ends with the pack launch that follows Adam
-ends = [i for i, r in enumerate(rows) if "pack_all" in r["Kernel_Name"]]
-assert len(ends) >= steps, (len(ends), steps)
-lo, hi = ends[-2] + 1, ends[-1] + 1
+# a step starts with the stem convolution of its forward pass
+starts = [i for i, r in enumerate(rows) if "stem_kernel" in r["Kernel_Name"]]
+assert len(starts) >= steps, (len(starts), steps)
+lo, hi = starts[-2], starts[-1]   # the last but one step (the last one has no successor to delimit it)
 step = rows[lo:hi]
 t0, t1 = int(step[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in step)
 print(f"last step: {len(step)} kernels, wall {(t1 - t0) / 1e6:.3f} ms")
@@ -31,3 +31,9 @@ for q, rs in byq.items():
     big = sorted(((g, a["Kernel_Name"][:50], b["Kernel_Name"][:50]) for g, a, b in zip(gaps, rs, rs[1:])), reverse=True)[:8]
     for g, a, b in big:
         print(f"    {g / 1e3:7.1f} us between {a.replace('(anonymous namespace)::', '')} -> {b.replace('(anonymous namespace)::', '')}")
+# tail: what each queue does in the last 600 us of the step
+for q, rs in byq.items():
+    print(f"queue {q} tail:")
+    for r in rs:
+        if int(r["End_Timestamp"]) > t1 - 600000:
+            print(f"   {(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} .. {(int(r['End_Timestamp']) - t0) / 1e3:9.1f} us  {r['Kernel_Name'].replace('(anonymous namespace)::', '')[:60]}")
