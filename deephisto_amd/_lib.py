@@ -85,6 +85,7 @@ SIGNATURES = {
     "dh_debug_dgrad_f32": (C.c_int, [_p, _p, _p, _p] + [_i32] * 7 + [_p]),
     "dh_debug_bn_f32": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "dh_debug_maxpool_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "dh_debug_bn_pool_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_stamps": (C.c_int, [_i32, _p]),
     "dh_profile_start": (C.c_int, [_i32, _i32]),
     "dh_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),

@@ -306,6 +306,11 @@ int dh_debug_bn_f32(const float* z_dev, const float* gamma_dev, const float* bet
                     float* stats_out_dev, int64_t rows, int32_t C, void* stream);
 int dh_debug_maxpool_f32(const float* x_dev, float* y_dev, const float* dy_dev, float* dx_dev, int32_t B, int32_t Hi, int32_t Wi,
                          int32_t C, void* stream);
+/* the stem's fused tail (float32 engine): pooled = maxpool3x3/2(relu(bn(z))) straight from z with batch statistics (+ positions); with
+ * dpool_dev: dz, dgamma, dbeta with the maxpool's gradient gathered inside the BN backward passes */
+int dh_debug_bn_pool_f32(const float* z_dev, const float* gamma_dev, const float* beta_dev, float* pooled_dev, uint8_t* idx_dev,
+                         const float* dpool_dev, float* dz_dev, float* dgamma_dev, float* dbeta_dev, int32_t B, int32_t Hi, int32_t Wi,
+                         int32_t C, void* stream);
 /* dh_debug_stamps: switch the 3x3-conv kernel to its cycle-stamped diagnostic variant and/or read
  * (and clear) its 8x8 table of summed phase cycles; out64_host may be NULL. */
 int dh_debug_stamps(int32_t enable, unsigned long long* out64_host);

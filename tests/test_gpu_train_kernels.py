@@ -164,6 +164,51 @@ def test_maxpool_forward_backward_kernels(dev, B, H, C):
     assert _rel(_nchw(dxd), want) <= 1e-6      # gradients are routed, not computed: only float32 sums of <= 4 terms
 
 
+@pytest.mark.parametrize("B,H,C", [(3, 112, 64), (2, 31, 64), (4, 16, 128)])
+def test_bn_pool_fused_stem_tail_f32(dev, B, H, C):
+    """The float32 engine's fused stem tail (bn_apply_pool_kernel; bn_pool_bwd_reduce / _apply: the maxpool's gradient gathered inside the BN
+    backward passes) against the unfused kernels it replaces -- pooled map bit for bit (the same float32 values are compared), dz / dgamma /
+    dbeta to summation order -- and against float64 autograd through relu(bn(z)) and max_pool2d."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(H + C)
+    z = (torch.randn(B, C, H, H, generator=g, dtype=torch.float64) * 1.3 + 0.2)
+    z[:, ::2] = (z[:, ::2] * 2).round() / 2     # half of the channels quantised: exact ties inside the windows
+    z.requires_grad_(True)
+    gamma = (0.5 + torch.rand(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    y = F.relu(F.batch_norm(z, None, None, gamma, beta, True, 0.1, 1e-5))
+    p = F.max_pool2d(y, 3, 2, 1)
+    Hp = p.shape[2]
+    dp = torch.randn(p.shape, generator=g, dtype=torch.float64)
+    dz_w, dg_w, db_w = torch.autograd.grad(p, (z, gamma, beta), dp)
+    zd, dpd = _nhwc(z.detach(), dev), _nhwc(dp, dev)
+    gmd, btd = gamma.detach().to(dev, torch.float32), beta.detach().to(dev, torch.float32)
+    pooled = torch.empty(B, Hp, Hp, C, dtype=torch.float32, device=dev)
+    idx = torch.empty(B, Hp, Hp, C, dtype=torch.uint8, device=dev)
+    dz = torch.empty_like(zd)
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    check(lib().dh_debug_bn_pool_f32(zd.data_ptr(), gmd.data_ptr(), btd.data_ptr(), pooled.data_ptr(), idx.data_ptr(), dpd.data_ptr(), dz.data_ptr(),
+                                     dg.data_ptr(), db.data_ptr(), B, H, H, C, None), "bn pool")
+    # the unfused chain: BN apply -> maxpool forward / backward -> BN backward (mask from y)
+    yd, dyd = torch.empty_like(zd), torch.empty_like(zd)
+    p2 = torch.empty_like(pooled)
+    dz2, g2 = torch.empty_like(zd), torch.empty_like(zd)
+    dg2, db2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    check(lib().dh_debug_bn_f32(zd.data_ptr(), gmd.data_ptr(), btd.data_ptr(), None, 1, yd.data_ptr(), None, None, None, None, None, None,
+                                B * H * H, C, None), "bn")
+    check(lib().dh_debug_maxpool_f32(yd.data_ptr(), p2.data_ptr(), dpd.data_ptr(), dyd.data_ptr(), B, H, H, C, None), "maxpool")
+    check(lib().dh_debug_bn_f32(zd.data_ptr(), gmd.data_ptr(), btd.data_ptr(), None, 1, yd.data_ptr(), dyd.data_ptr(), dz2.data_ptr(), g2.data_ptr(),
+                                dg2.data_ptr(), db2.data_ptr(), None, B * H * H, C, None), "bn bwd")
+    assert torch.equal(pooled, p2)
+    assert _rel(dz.cpu(), dz2.cpu()) <= 1e-6 and _rel(dg.cpu(), dg2.cpu()) <= 1e-6 and _rel(db.cpu(), db2.cpu()) <= 1e-6
+    # float64 reference
+    assert _rel(_nchw(pooled), p.detach()) <= TOL
+    assert _rel(dg.cpu(), dg_w) <= TOL and _rel(db.cpu(), db_w) <= TOL
+    assert _rel(_nchw(dz), dz_w) <= 2 * TOL
+    ii = idx.cpu().long()
+    assert int(ii.max()) <= 8
+
+
 # ---- bf16 engine (train2): the GEMM-shaped kernels on their own ------------------------------------------------------
 def _bf(t):
     return t.bfloat16().float()
