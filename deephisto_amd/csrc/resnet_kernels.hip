@@ -296,20 +296,40 @@ __global__ __launch_bounds__(256, 2) void stem_kernel(const StemParams p) {
 
   int ty0 = 0, tx0 = 0;
   if constexpr (SRC_U8) { ty0 = p.yx[2 * b]; tx0 = p.yx[2 * b + 1]; }
-  for (int i = tid; i < STEM_ROWS * STEM_ROWE; i += 256) {
+  // window staging in two phases: every load of the thread's 19 elements is issued before the first LDS store (a load + store per
+  // iteration of a rolled loop serialised on the load latency: 18 round trips per tile, ~90 % of the bf16 kernel's time in training)
+  constexpr int NE = STEM_ROWS * STEM_ROWE;
+  auto fetch = [&](int i) __attribute__((always_inline)) -> float {   // element i of the window image (raw value; 0 outside the image)
     const int r = i / STEM_ROWE, e = i % STEM_ROWE;
-    float v = 0.f;
-    if (e >= 1 && e < STEM_REAL) {
-      const int q = e - 1, ix = ix0 + q / 3, c = q % 3, iy = iy0 + r;
-      if (iy >= 0 && iy < p.P && ix >= 0 && ix < p.P) {
-        if constexpr (SRC_U8)
-          v = div255f(p.slide[(int64_t)(ty0 + iy) * p.row_bytes + (int64_t)(tx0 + ix) * 3 + c]);
-        else
-          v = p.x_nchw[(((int64_t)b * 3 + c) * p.P + iy) * p.P + ix];
-      }
+    const int q = e - 1, ix = ix0 + q / 3, c = q % 3, iy = iy0 + r;
+    float x = 0.f;
+    if (i < NE && e >= 1 && e < STEM_REAL && iy >= 0 && iy < p.P && ix >= 0 && ix < p.P) {
+      if constexpr (SRC_U8) x = (float)p.slide[(int64_t)(ty0 + iy) * p.row_bytes + (int64_t)(tx0 + ix) * 3 + c];
+      else x = p.x_nchw[(((int64_t)b * 3 + c) * p.P + iy) * p.P + ix];
     }
-    if constexpr (ESZ == 2) reinterpret_cast<uint16_t*>(e_lds)[i] = (uint16_t)f32_to_bf16(v);
-    else e_lds[i] = v;
+    return x;
+  };
+  if constexpr (ESZ == 2) {   // element pairs: one 4-byte LDS store per two elements
+    constexpr int NP = NE / 2, NIT = (NP + 255) / 256;
+    float v0[NIT], v1[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) { const int j = tid + 256 * k; v0[k] = fetch(j < NP ? 2 * j : NE); v1[k] = fetch(j < NP ? 2 * j + 1 : NE); }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int j = tid + 256 * k;
+      const float x0 = SRC_U8 ? div255f((uint32_t)v0[k]) : v0[k], x1 = SRC_U8 ? div255f((uint32_t)v1[k]) : v1[k];
+      if (j < NP) reinterpret_cast<uint32_t*>(e_lds)[j] = f32_to_bf16(x0) | (f32_to_bf16(x1) << 16);
+    }
+  } else {
+    constexpr int NIT = (NE + 255) / 256;
+    float v[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) v[k] = fetch(tid + 256 * k);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = tid + 256 * k;
+      if (i < NE) reinterpret_cast<float*>(e_lds)[i] = SRC_U8 ? div255f((uint32_t)v[k]) : v[k];
+    }
   }
   __syncthreads();
 
