@@ -124,7 +124,9 @@ def train_hbm_bytes(arch: str, dtype: str, B: int, P: int) -> dict:
     that reads or writes it; operand re-reads inside a kernel, weights and the slab buffers of the weight gradients are
     left out).  Per conv + BN: forward  conv (in, Z) | statistics (Z; none for a bf16 1x1 conv: GEMM epilogue) | apply
     (Z [, identity], Y);  backward  BN reduce (Z, dY [, Y]) | BN apply (Z, dY [, Y], dZ [, masked copy]) | wgrad (X, dZ)
-    | dgrad (dZ, dX [, identity gradient]).  Plus max-pool, Adam (7 x 4 B per parameter) and the weight re-packing."""
+    | dgrad (dZ, dX [, identity gradient]).  The stem (round 3): conv (x, Z) | statistics (Z) | BN + ReLU + max-pool in one pass
+    (Z, pooled, positions); backward BN reduce and BN apply gather the pooled gradient themselves (Z, pooled gradient, positions
+    [, dZ]) | wgrad (x, dZ).  Plus Adam (7 x 4 B per parameter) and the weight re-packing."""
     e = 4 if dtype == "f32" else 2
     H1 = (P + 6 - 7) // 2 + 1
     H2 = (H1 + 2 - 3) // 2 + 1
@@ -145,7 +147,11 @@ def train_hbm_bytes(arch: str, dtype: str, B: int, P: int) -> dict:
             for blk in range(nb):
                 st = 2 if (blk == 0 and s > 0) else 1
                 ho = (h + 2 - 3) // st + 1
-                convs += [(cin, w, 1, h, h, False, False), (w, w, 3, h, ho, False, False), (w, 4 * w, 1, ho, ho, True, False)]
+                # bf16 engine: the 3x3 conv's BN gets its backward sums from the dgrad GEMM of conv3 ("fused"); the join BN of a block
+                # whose successor has no downsample gets them from that successor's first dgrad GEMM, which also applies the ReLU
+                # mask ("premasked": no reduce pass, the apply pass reads neither Y nor writes the masked copy)
+                convs += [(cin, w, 1, h, h, False, False), (w, w, 3, h, ho, False, "fused"),
+                          (w, 4 * w, 1, ho, ho, True, "premasked" if blk + 1 < nb else False)]
                 if st != 1 or cin != 4 * w:
                     convs.append((cin, 4 * w, 1, h, ho, False, True))
                 h, cin = ho, 4 * w
@@ -153,14 +159,21 @@ def train_hbm_bytes(arch: str, dtype: str, B: int, P: int) -> dict:
     act = 0
     for ci, co, ks, hi, ho, join, ds in convs:
         I, O = B * hi * hi * ci * (4 if ks == 7 else e), B * ho * ho * co * e
+        if ks == 7:
+            Op, Ib = B * H2 * H2 * 64 * e, B * H2 * H2 * 64
+            act += (I + O) + O + (O + Op + Ib) + (O + Op + Ib) + (O + Op + Ib + O) + (I + O)
+            continue
         fused_stats = dtype == "bf16" and ks == 1
         fwd = I + O + (0 if fused_stats else O) + O + (O if join else 0) + O
-        bwd = (2 + (1 if join else 0)) * O + (2 + (1 if join else 0)) * O + O + (O if join else 0) + (I + O) + (O + (0 if ks == 7 else I))
+        if ds == "premasked":
+            bwd = 0 + 2 * O + O + (I + O) + (O + I)
+        else:
+            reduce_pass = 0 if ds == "fused" else (2 + (1 if join else 0)) * O
+            bwd = reduce_pass + (2 + (1 if join else 0)) * O + O + (O if join else 0) + (I + O) + (O + I)
         act += fwd + bwd
-    pool = B * H1 * H1 * 64 * e * 2 + B * H2 * H2 * 64 * e * 2
     adam = 7 * 4 * n_params
     pack = (4 + 2 * e) * n_params
-    return {"activation_passes": act + pool, "adam": adam, "weight_packing": pack, "total": act + pool + adam + pack}
+    return {"activation_passes": act, "adam": adam, "weight_packing": pack, "total": act + adam + pack}
 
 
 
