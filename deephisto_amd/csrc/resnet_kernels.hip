@@ -722,11 +722,11 @@ std::map<std::vector<int>, Conv3Tables> g_conv3_tables;
 constexpr size_t CONV3_TABLE_CAP = 256;
 
 template <int STRIDE, int NT, int WAVES, int ESZ, int MT>
-int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out) {
+int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out, int grid_override = 0) {
   constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
   const std::vector<int> key = {current_device(), STRIDE, NT, WAVES, MT, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi,
                                 p.Cin, p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes, p.Ho, p.Wo, p.Cout, p.out_px,
-                                p.out_cb, (int)(p.o_img & 0x7FFFFFFF), (int)(p.o_img >> 31), p.o_row, p.o_px, p.o_base};
+                                p.out_cb, (int)(p.o_img & 0x7FFFFFFF), (int)(p.o_img >> 31), p.o_row, p.o_px, p.o_base, grid_override, p.iters};
   std::lock_guard<std::mutex> lk(g_host_mu);
   auto it = g_conv3_tables.find(key);
   if (it != g_conv3_tables.end()) { *out = it->second; return DH_OK; }
@@ -811,7 +811,7 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
   // no longer fit one L2 (they come from the Infinity Cache instead).
   // Either way a workgroup keeps its cout block for all iterations (resident-weight variants rely on it).
   const int tiles_per_img = p.tiles_y * p.tiles_x;
-  const int grid = std::min(256, p.ntiles), n_pt = p.ntiles / ncb;
+  const int grid = grid_override > 0 ? grid_override : std::min(256, p.ntiles), n_pt = p.ntiles / ncb;   // (override: a share of a merged launch)
   const bool xcd_group = ncb > 1 && grid == 256 && 32 % ncb == 0 && (int64_t)p.Cout * p.Cin * 9 * ESZ <= (1 << 23);
   std::vector<int4> tile((size_t)p.iters * grid);
   for (int it = 0; it < p.iters; ++it)
@@ -1007,16 +1007,125 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
 // (The classes write disjoint pixels and each fills at most half the chip at batch 64; running them on four streams, forked and
 // joined by events, was measured SLOWER: float32 ResNet-18 step 9.64 -> 10.63 ms -- six cross-stream dependencies per convolution
 // cost more than the idle CUs.  One stream.)
+template <typename T, int NT, int WAVES, int MT>
+int launch_dgrad_s2_merged_cfg(Conv3Params (&pc)[4], const int (&tiles_c)[4], const ConvLayer& L, hipStream_t st) {
+  // pc[k]: the parameters of class order[k] (same tile shape, own Ho x Wo and output base); one launch over all of them
+  static const int order[4] = {3, 1, 2, 0}, taps[4] = {4, 2, 2, 1};
+  constexpr int MAXJ = NT == 2 ? 6 : 4;
+  const Conv3Params& p0 = pc[0];
+  const int win_bytes = p0.IMGS * p0.HR * p0.HP * CHUNK_BYTES;
+  const size_t lds = 2 * ((size_t)9 * SLAB_TAP + ((win_bytes + 1023) & ~1023)) + 1024;
+  const int n_win_instr = (p0.IMGS * p0.HR * p0.HP + 15) / 16;
+  DH_REQUIRE(n_win_instr <= MAXJ * WAVES, "dgrad s2: staging window too large for the DMA plan");
+  DH_REQUIRE(lds <= 160 * 1024, "dgrad s2: LDS budget exceeded (%zu B)", lds);
+  DH_REQUIRE(p0.IMGS * p0.TH * p0.TW == (WAVES * MT / 2) * NT * 32, "dgrad s2: tile/pixel mismatch");
+  DH_REQUIRE(L.cin * (int)sizeof(T) >= 2 * CHUNK_BYTES, "dgrad s2: needs at least two channel chunks");
+  // workgroups per class: one at a time to the class whose (tiles per workgroup) x (taps) is largest
+  int wg[4] = {0, 0, 0, 0}, total = 0;
+  for (int k = 0; k < 4; ++k) if (tiles_c[k] > 0) { wg[k] = 1; ++total; }
+  auto cost = [&](int k) { return wg[k] > 0 ? ((tiles_c[k] + wg[k] - 1) / wg[k]) * taps[k] : 0; };
+  while (total < 256) {
+    int best = -1;
+    for (int k = 0; k < 4; ++k)
+      if (wg[k] > 0 && wg[k] < tiles_c[k] && (best < 0 || cost(k) > cost(best))) best = k;
+    if (best < 0) break;
+    ++wg[best]; ++total;
+  }
+  S2ClassSched sch;
+  sch.first[0] = 0;
+  for (int k = 0; k < 4; ++k) {
+    sch.first[k + 1] = sch.first[k] + wg[k];
+    sch.iters[k] = 0; sch.lane[k] = nullptr; sch.tile[k] = nullptr; sch.mask[k] = nullptr;
+    if (wg[k] == 0) continue;
+    Conv3Params& p = pc[k];
+    p.n_win_instr = n_win_instr;
+    p.ntiles = tiles_c[k];
+    p.iters = (tiles_c[k] + wg[k] - 1) / wg[k];
+    Conv3Tables tb;
+    int rc = conv3_tables<1, NT, WAVES, (int)sizeof(T), MT>(p, L.cout / 64, 0, &tb, wg[k]);
+    if (rc) return rc;
+    sch.iters[k] = p.iters; sch.lane[k] = tb.lane; sch.tile[k] = tb.tile; sch.mask[k] = tb.mask;
+  }
+  (void)order;
+  Conv3Params pl = pc[0];
+  pl.n_win_instr = n_win_instr;
+  pl.lane_tab = nullptr; pl.tile_tab = nullptr; pl.mask_tab = nullptr; pl.stamps = nullptr;
+  if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_s2dgrad_kernel<T, NT, WAVES, MT>), 160 * 1024)) return rc;
+  hipLaunchKernelGGL((conv3x3_s2dgrad_kernel<T, NT, WAVES, MT>), dim3(sch.first[4]), dim3(WAVES * 64), lds, st, pl, sch);
+  DH_LAUNCH_CHECK();
+  return DH_OK;
+}
+
+// Data gradient of a 3x3 / stride-2 / pad-1 convolution WITHOUT the zero-upsampled copy of dZ: four stride-1 convolutions, one per
+// parity class of the dX pixel (1, 2, 2 and 4 taps of the flipped + transposed operator `L.w_dev`; conv3x3.inc, CLS), side by side in ONE
+// launch (conv3x3_s2dgrad_kernel).  dz is [B][Ho][Wo][L.cin], dx (and res, the gradient joining from another branch, may be null)
+// [B][Hi][Wi][L.cout], NHWC.  (History: four launches on one stream -- each fills a fraction of the chip at batch 64; four streams forked
+// and joined by events -- slower still, 9.64 -> 10.63 ms per float32 step.  DH_DGRAD_S2_SERIAL=1 keeps the four launches for A/B.)
 template <typename T>
 int launch_dgrad_s2(const ConvLayer& L, const void* dz, const void* res, void* dx, int B, int Ho, int Wo, int Hi, int Wi, hipStream_t st) {
   DH_REQUIRE(Ho == (Hi + 2 - 3) / 2 + 1 && Wo == (Wi + 2 - 3) / 2 + 1, "dgrad s2: %dx%d is not the stride-2 output of %dx%d", Ho, Wo, Hi, Wi);
   int rc;
   const int re = (Hi + 1) / 2, ro = Hi / 2, ce = (Wi + 1) / 2, co = Wi / 2;   // rows / columns of dX with even / odd index
-  if (ro > 0 && co > 0 && (rc = launch_conv3x3<T, 1, 3>(L, dz, res, dx, B, Ho, Wo, false, st, ro, co, nullptr, nullptr, false, Hi, Wi))) return rc;
-  if (re > 0 && co > 0 && (rc = launch_conv3x3<T, 1, 1>(L, dz, res, dx, B, Ho, Wo, false, st, re, co, nullptr, nullptr, false, Hi, Wi))) return rc;
-  if (ro > 0 && ce > 0 && (rc = launch_conv3x3<T, 1, 2>(L, dz, res, dx, B, Ho, Wo, false, st, ro, ce, nullptr, nullptr, false, Hi, Wi))) return rc;
-  if (re > 0 && ce > 0 && (rc = launch_conv3x3<T, 1, 0>(L, dz, res, dx, B, Ho, Wo, false, st, re, ce, nullptr, nullptr, false, Hi, Wi))) return rc;
-  return DH_OK;
+  static const bool serial = getenv("DH_DGRAD_S2_SERIAL") != nullptr;
+  if (serial) {
+    if (ro > 0 && co > 0 && (rc = launch_conv3x3<T, 1, 3>(L, dz, res, dx, B, Ho, Wo, false, st, ro, co, nullptr, nullptr, false, Hi, Wi))) return rc;
+    if (re > 0 && co > 0 && (rc = launch_conv3x3<T, 1, 1>(L, dz, res, dx, B, Ho, Wo, false, st, re, co, nullptr, nullptr, false, Hi, Wi))) return rc;
+    if (ro > 0 && ce > 0 && (rc = launch_conv3x3<T, 1, 2>(L, dz, res, dx, B, Ho, Wo, false, st, ro, ce, nullptr, nullptr, false, Hi, Wi))) return rc;
+    if (re > 0 && ce > 0 && (rc = launch_conv3x3<T, 1, 0>(L, dz, res, dx, B, Ho, Wo, false, st, re, ce, nullptr, nullptr, false, Hi, Wi))) return rc;
+    return DH_OK;
+  }
+  // one tile shape for all classes, picked on the largest (even, even) class: the largest tile that still gives the launch 256 tiles
+  static const int order[4] = {3, 1, 2, 0};
+  const int rows_of[4] = {re, re, ro, ro}, cols_of[4] = {ce, co, ce, co};   // by class id (py, px) = (id >> 1, id & 1)
+  struct Cand { int th, tw, imgs, hp, variant; };
+  Cand cands[4];
+  int nc = 0;
+  if (ce > 16) {
+    const int slots_a = ((re + 15) / 16) * ((ce + 31) / 32), slots_b = ((re + 7) / 8) * ((ce + 63) / 64);
+    if (slots_b < slots_a) cands[nc++] = {8, 64, 1, 66, 0};
+    else cands[nc++] = {16, 32, 1, 34, 0};
+    cands[nc++] = {16, 16, 1, 18, 1};
+  } else if (ce > 8) {
+    cands[nc++] = {16, 16, 2, 18, 0};
+    cands[nc++] = {16, 16, 1, 18, 1};
+    cands[nc++] = {8, 8, 2, 12, 2};
+  } else {
+    cands[nc++] = {8, 8, 4, 12, 1};
+    cands[nc++] = {8, 8, 2, 12, 2};
+  }
+  auto tiles_of = [&](const Cand& c, int rows, int cols) {
+    return rows > 0 && cols > 0 ? ((B + c.imgs - 1) / c.imgs) * ((rows + c.th - 1) / c.th) * ((cols + c.tw - 1) / c.tw) * (L.cout / 64) : 0;
+  };
+  int pick = nc - 1;
+  for (int i = 0; i < nc; ++i) {
+    int tot = 0;
+    for (int id = 0; id < 4; ++id) tot += tiles_of(cands[i], rows_of[id], cols_of[id]);
+    if (tot >= 256) { pick = i; break; }
+  }
+  const Cand& cd = cands[pick];
+  Conv3Params pc[4];
+  int tiles_c[4];
+  const void* zp = nullptr;
+  if (int zrc = zero_page(&zp)) return zrc;
+  for (int k = 0; k < 4; ++k) {
+    const int id = order[k], rows = rows_of[id], cols = cols_of[id];
+    Conv3Params& p = pc[k];
+    p.in_px_bytes = L.cin * (int)sizeof(T); p.in_chunk_bytes = CHUNK_BYTES;
+    p.out_px = L.cout; p.out_mt = 32; p.out_cb = 64;
+    p.o_img = (int64_t)Hi * Wi * L.cout; p.o_row = 2 * Wi * L.cout; p.o_px = 2 * L.cout;
+    p.o_base = ((id >> 1) * Wi + (id & 1)) * L.cout;
+    p.ds_w = nullptr; p.ds_scale = nullptr; p.ds_shift = nullptr; p.ds_out = nullptr;
+    p.in = dz; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = dx;
+    p.B = B; p.Hi = Ho; p.Wi = Wo; p.Cin = L.cin; p.Cout = L.cout; p.Ho = rows; p.Wo = cols;
+    p.relu = 0; p.zero_page = zp; p.stamps = nullptr;
+    p.HPH = 0; p.TH = cd.th; p.TW = cd.tw; p.IMGS = cd.imgs; p.HP = cd.hp; p.HR = cd.th + 2; p.HC = cd.tw + 2;
+    p.tiles_y = (rows + cd.th - 1) / cd.th; p.tiles_x = (cols + cd.tw - 1) / cd.tw;
+    p.lane_tab = nullptr; p.tile_tab = nullptr; p.mask_tab = nullptr; p.ntiles = 0; p.iters = 0; p.n_win_instr = 0;
+    tiles_c[k] = tiles_of(cd, rows, cols);
+  }
+  return cd.variant == 0 ? launch_dgrad_s2_merged_cfg<T, 2, 8, 2>(pc, tiles_c, L, st)
+       : cd.variant == 1 ? launch_dgrad_s2_merged_cfg<T, 1, 8, 2>(pc, tiles_c, L, st)
+                         : launch_dgrad_s2_merged_cfg<T, 1, 8, 1>(pc, tiles_c, L, st);
 }
 
 template <typename T>
