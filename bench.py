@@ -226,7 +226,8 @@ def train_leg(dev, steps: int, arch: str = "resnet18", dtype: str = "f32", group
                             "hbm_note": "algorithmic bytes of the engine's passes (train_hbm_bytes) over wall time: the BN / pooling / "
                                         "Adam passes are HBM-bound, the convolutions MFMA-bound; both fractions describe the same step"})
     if world > 1:
-        out["config"]["parallelism"] = f"dp{world}: bucketed (~25 MB) all-reduce overlapped with backward"
+        from deephisto_amd.models.patch_cls_simple.ddp import default_wire
+        out["config"]["parallelism"] = f"dp{world}: bucketed (~25 MB) {default_wire()} all-reduce overlapped with backward (DH_DDP_WIRE=bf16 halves the bytes)"
         out["buckets"] = [c for _, _, c in getattr(getattr(model, "_engine", model), "overlap_log", [])]
     return out
 

@@ -66,6 +66,8 @@ SIGNATURES = {
     "dh_train2_forward": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _p]),
     "dh_train2_backward": (C.c_int, [_p, _p, _p]),
     "dh_train2_adam_step": (C.c_int, [_p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
+    "dh_grad_pack_bf16": (C.c_int, [_p, _p, _i64, _p]),
+    "dh_grad_unpack_bf16": (C.c_int, [_p, _p, _i64, C.c_float, _p]),
     "dh_train2_backward_adam": (C.c_int, [_p, _p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
     "dh_train2_debug_act": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _p]),
     "dh_debug_gemm1x1_bf16": (C.c_int, [_p, _p, _p, _p, _i64] + [_i32] * 8 + [_p]),

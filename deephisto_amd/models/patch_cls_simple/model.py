@@ -310,7 +310,7 @@ class ResNet18HIP(nn.Module):
             self._native_ahead = True
             return loss, logits
         if not single:
-            red = BucketReducer(self.flat_gradients(x.device), group)
+            red = BucketReducer(self.flat_gradients(x.device), group, getattr(self, "ddp_wire", None))   # None: DH_DDP_WIRE (f32 | bf16)
             cb = BUCKET_CB(lambda bucket, off, cnt, _user: red.on_bucket(bucket, off, cnt))
             check(lib().dh_resnet18_set_buckets(self._handle, int(bucket_bytes), cb, None, None), "dh_resnet18_set_buckets")
         try:

@@ -39,6 +39,7 @@ class Train2Engine:
         self.native_ahead = False  # the library's parameters are newer than the nn.Parameters (fused train_step)
         self._cb = None
         self.overlap_log = []      # (bucket, offset, count) in launch order of the last data-parallel backward (tests)
+        self.ddp_wire = None        # gradient wire format of data-parallel steps: None = DH_DDP_WIRE (default f32), "f32", "bf16"
         self.fuse_optimizer = True  # single-rank train_step: dh_train2_backward_adam (False: backward, then adam_step; tests)
 
     # ---- handle and parameter traffic -------------------------------------------------------------------
@@ -139,7 +140,7 @@ class Train2Engine:
         return out
 
     def _arm_overlap(self, dev, group, bucket_bytes):
-        red = BucketReducer(self.flat(1, dev), group)
+        red = BucketReducer(self.flat(1, dev), group, self.ddp_wire)
         # called inside dh_train2_backward right after the kernels completing a bucket were enqueued on the current stream
         self._cb = BUCKET_CB(lambda bucket, off, cnt, _user: red.on_bucket(bucket, off, cnt))   # keep the trampoline alive
         n = C.c_int32()

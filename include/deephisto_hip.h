@@ -222,6 +222,10 @@ int dh_train2_tensor(dh_train2* net, const char* name, int32_t kind, void* ptr, 
 int dh_train2_flat(dh_train2* net, int32_t kind, void** ptr_out, int64_t* n_out);
 int dh_train2_set_buckets(dh_train2* net, int64_t bucket_bytes, dh_bucket_cb cb, void* user, int32_t* n_buckets_out);
 int dh_train2_bucket(dh_train2* net, int32_t i, int64_t* offset, int64_t* count);
+/* optional bf16 wire format of the gradient exchange (either engine's arena; n % 4 == 0): float32 -> bf16 (round to nearest even)
+ * before a bucket's all-reduce, bf16 sums -> float32 * scale (1 / world) after it.  Halves the bytes on xGMI. */
+int dh_grad_pack_bf16(const float* src_dev, uint16_t* dst_dev, int64_t n, void* stream);
+int dh_grad_unpack_bf16(const uint16_t* src_dev, float* dst_dev, int64_t n, float scale, void* stream);
 int dh_train2_forward(dh_train2* net, const float* x_dev, int64_t n, int32_t patch, float* logits_dev,
                       int32_t training, void* stream);
 int dh_train2_backward(dh_train2* net, const float* dlogits_dev, void* stream);

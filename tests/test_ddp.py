@@ -150,6 +150,83 @@ def test_bucket_reducer_equals_one_allreduce_gloo_cpu():
     np.testing.assert_array_equal(got[0][1], got[1][1])
 
 
+def _bucket_bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deephisto_amd.models.patch_cls_simple.ddp import BucketReducer, allreduce_mean_
+    g = torch.Generator().manual_seed(17 + rank)
+    flat = torch.randn(10_000, generator=g)
+    want = allreduce_mean_(flat.clone())
+    red = BucketReducer(flat, None, wire="bf16")
+    for b, (off, cnt) in enumerate([(7000, 3000), (2500, 4500), (0, 2500)]):
+        red.on_bucket(b, off, cnt)
+    out = red.finish()
+    q.put((rank, out.numpy(), want.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_reducer_bf16_wire_gloo_cpu():
+    """bf16 wire format of the bucketed exchange (host tensors, gloo): every rank ends with the SAME averaged gradients (the ranks
+    reduce identical bf16 sums), within bf16 rounding of the float32 mean."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bucket_bf16_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = [q.get(timeout=120) for _ in range(world)]
+    [p.join(timeout=60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    np.testing.assert_array_equal(got[0][1], got[1][1])
+    for _, out, want in got:
+        assert np.abs(out - want).max() <= 2.0 ** -7 * np.abs(want).max() + 2.0 ** -8 * 4.0
+
+
+def _gpu_bf16_wire_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    from oracle import resnet50 as oracle_net
+    dev = torch.device("cuda:0")
+    ref = oracle_net.seeded_model(4, 5, perturb_bn=True)
+    g = torch.Generator().manual_seed(300 + rank)
+    x = torch.rand(4, 3, 64, 64, generator=g).to(dev)
+    y = torch.randint(0, 5, (4,), generator=g).to(dev)
+    grads = {}
+    for wire in ("f32", "bf16"):
+        m = get_model(5, arch="resnet50")
+        m.load_state_dict(ref.state_dict())
+        m.to(dev).train()
+        m._engine.ddp_wire = wire
+        loss, _ = m.train_step(x, y, lr=1e-4)
+        grads[wire] = m.flat_gradients(dev).clone().cpu()
+        if wire == "bf16":
+            sd = m.state_dict()
+            out = (sd["fc.weight"].cpu().numpy(), sd["layer1.0.conv1.weight"].cpu().numpy())
+        del m
+    rel = float((grads["bf16"] - grads["f32"]).norm() / grads["f32"].norm())
+    q.put((rank, rel, grads["bf16"].numpy(), out[0], out[1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ddp_bf16_wire_keeps_replicas_identical(built_lib):
+    """Two ranks on one GPU (gloo), ResNet-50 bf16 engine, DH_DDP_WIRE=bf16 semantics through `ddp_wire`: the averaged gradients are the
+    float32 exchange's within bf16 rounding (relative L2 <= 4e-3) and both replicas hold identical gradients and parameters."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gpu_bf16_wire_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    [p.join(timeout=120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    for r in range(world):
+        assert got[r][1] <= 4e-3, got[r][1]
+    assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3]) and np.array_equal(got[0][4], got[1][4])
+
+
 def _gpu_bf16_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
