@@ -74,6 +74,7 @@ SIGNATURES = {
     "dh_debug_gemm1x1_fused_bf16": (C.c_int, [_p] * 7 + [_i64] + [_i32] * 8 + [_p]),
     "dh_debug_gemm1x1_bwdsums_bf16": (C.c_int, [_p] * 10 + [_i32, _p, _i64, _i32, _i32, _p]),
     "dh_debug_bn2_bf16": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _i64, _i32, _p]),
+    "dh_debug_stem_wgrad_bf16": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     "dh_debug_bn2_pool_bf16": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_maxpool2_bf16": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_upsample2_add_bf16": (C.c_int, [_p, _p] + [_i32] * 6 + [_p]),

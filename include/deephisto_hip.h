@@ -273,6 +273,7 @@ int dh_debug_upsample2_add_bf16(const uint16_t* t_dev, uint16_t* dx_dev, int32_t
                                 int32_t C, void* stream);
 int dh_debug_avgpool_fc_dgrad2(const float* dlogits_dev, const float* w_dev, uint16_t* dx_dev, int32_t B, int32_t HW, int32_t C,
                                int32_t n_cls, void* stream);
+int dh_debug_stem_wgrad_bf16(const uint16_t* dz_dev, const float* x_nchw_dev, float* dw_dev, int32_t B, int32_t P, void* stream);
 int dh_debug_wgrad_bf16(const uint16_t* dz_dev, const uint16_t* x_dev, float* dw_dev, int32_t B, int32_t Hi, int32_t Wi,
                         int32_t cin, int32_t cout, int32_t ks, int32_t stride, int32_t repeat, void* stream);
 

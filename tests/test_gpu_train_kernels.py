@@ -77,6 +77,29 @@ def test_stem_wgrad_kernel(dev, B, P):
     assert _rel(dw.cpu(), want) <= TOL
 
 
+@pytest.mark.parametrize("B,P", [(3, 64), (2, 224), (5, 96), (64, 224)])
+def test_stem_wgrad_bf16_kernel(dev, B, P):
+    """The bf16 engine's stem weight gradient (stem_wgrad_bf16_kernel: 16 output pixels per bf16 MFMA, x rounded to bf16 on its way into
+    LDS) against float64 on the SAME bf16 operands: float32 accumulation of exact bf16 products, so 1e-5 relative; two runs equal bits."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(P + B)
+    x = torch.rand(B, 3, P, P, generator=g)
+    xb = x.bfloat16().double()
+    w = torch.zeros(64, 3, 7, 7, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xb, w, None, 2, 3)
+    dz = torch.randn(y.shape, generator=g).bfloat16()
+    (want,) = torch.autograd.grad(y, w, dz.double())
+    xd = x.to(dev).contiguous()
+    dzd = dz.permute(0, 2, 3, 1).contiguous().to(dev)
+    outs = []
+    for _ in range(2):
+        dw = torch.empty(64, 3, 7, 7, dtype=torch.float32, device=dev)
+        check(lib().dh_debug_stem_wgrad_bf16(dzd.data_ptr(), xd.data_ptr(), dw.data_ptr(), B, P, None), "stem wgrad bf16")
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert _rel(outs[0], want) <= 1e-5
+
+
 @pytest.mark.parametrize("ks,stride,cin,cout,B,H,res", [
     (3, 1, 64, 64, 2, 32, True), (3, 1, 256, 256, 3, 14, False), (3, 2, 64, 128, 2, 32, False),
     (3, 2, 256, 512, 3, 14, False), (1, 2, 64, 128, 2, 32, True), (1, 2, 256, 512, 3, 14, True),
