@@ -165,6 +165,8 @@ def train_hbm_bytes(arch: str, dtype: str, B: int, P: int) -> dict:
             continue
         fused_stats = dtype == "bf16" and ks == 1
         fwd = I + O + (0 if fused_stats else O) + O + (O if join else 0) + O
+        if ds is True and dtype == "bf16":   # the downsample branch's BN is applied inside the join BN's pass: no apply pass of its own
+            fwd -= 2 * O
         if ds == "premasked":
             bwd = 0 + 2 * O + O + (I + O) + (O + I)
         else:

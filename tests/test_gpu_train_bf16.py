@@ -210,6 +210,32 @@ def test_fused_backward_adam_equals_backward_then_adam(dev, arch):
         assert la == lb and torch.equal(ga, gb)
 
 
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_join_bn_fusion_is_bit_identical(dev, arch, monkeypatch):
+    """The downsample branch's BN applied inside the join BN's pass (bn2_apply_join_kernel: the branch value rounded to bf16 where the
+    separate pass would have stored it) against the two-pass form (DH_T2_JOIN=0, read when the engine is created): identical bits."""
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(6, 3, 96, 96, generator=g).to(dev)
+    y = torch.randint(0, 5, (6,), generator=g).to(dev)
+    runs = []
+    for join in ("1", "0"):
+        monkeypatch.setenv("DH_T2_JOIN", join)
+        torch.manual_seed(5)
+        m = get_model(5, "bf16", arch=arch).to(dev).train()
+        trace = []
+        for _ in range(3):
+            loss, logits = m.train_step(x, y, lr=1e-3)
+            trace.append((float(loss), logits.clone()))
+        eng = m._bf16_engine() if arch == "resnet18" else m._engine
+        runs.append((trace, eng.flat(0, dev).clone()))
+        del m
+    (ta, pa), (tb, pb) = runs
+    for (la, ga), (lb, gb) in zip(ta, tb):
+        assert la == lb and torch.equal(ga, gb)
+    assert torch.equal(pa, pb)
+
+
 def test_bench_shape_runs_and_learns(dev):
     """64 x 224^2 (BASELINE configs[4] per-rank batch): every layer takes its large-launch path; the loss on a fixed batch
     must fall (no CPU oracle at this size: ResNet-50 forward + backward of 64 images is minutes of host time)."""
