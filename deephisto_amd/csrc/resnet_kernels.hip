@@ -1074,6 +1074,30 @@ int launch_dgrad_s2(const ConvLayer& L, const void* dz, const void* res, void* d
     if (re > 0 && ce > 0 && (rc = launch_conv3x3<T, 1, 0>(L, dz, res, dx, B, Ho, Wo, false, st, re, ce, nullptr, nullptr, false, Hi, Wi))) return rc;
     return DH_OK;
   }
+  static const bool per_class = getenv("DH_DGRAD_S2_MERGED") != nullptr;   // A/B: the merged class launch instead of the all-classes kernel
+  if (!per_class && Hi % 2 == 0 && Wi % 2 == 0) {
+    // all four classes from one staged dZ window (conv3x3.inc, CLS == 4): a stride-1 convolution over the dZ grid with four accumulator
+    // sets; 256- or 128-pixel tiles (NT = 1)
+    Conv3Params p;
+    p.in_px_bytes = L.cin * (int)sizeof(T); p.in_chunk_bytes = CHUNK_BYTES;
+    p.out_px = L.cout; p.out_mt = 32; p.out_cb = 64;
+    p.o_img = (int64_t)Hi * Wi * L.cout; p.o_row = 2 * Wi * L.cout; p.o_px = 2 * L.cout; p.o_base = 0;
+    for (int c = 0; c < 4; ++c) p.cls_base[c] = ((c >> 1) * Wi + (c & 1)) * L.cout;
+    p.ds_w = nullptr; p.ds_scale = nullptr; p.ds_shift = nullptr; p.ds_out = nullptr;
+    p.in = dz; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = dx;
+    p.B = B; p.Hi = Ho; p.Wi = Wo; p.Cin = L.cin; p.Cout = L.cout; p.Ho = re; p.Wo = ce;
+    p.relu = 0; p.stamps = nullptr; p.HPH = 0;
+    if ((rc = zero_page(&p.zero_page))) return rc;
+    struct CandA { int th, tw, imgs, hp, mt; };
+    CandA ca[2];
+    if (ce > 8) { ca[0] = {16, 16, 1, 18, 2}; ca[1] = {8, 8, 2, 12, 1}; }
+    else { ca[0] = {8, 8, 4, 12, 2}; ca[1] = {8, 8, 2, 12, 1}; }
+    auto ntiles = [&](const CandA& c) { return ((B + c.imgs - 1) / c.imgs) * ((re + c.th - 1) / c.th) * ((ce + c.tw - 1) / c.tw) * (L.cout / 64); };
+    const CandA& cd = ntiles(ca[0]) >= 256 ? ca[0] : ca[1];
+    p.TH = cd.th; p.TW = cd.tw; p.IMGS = cd.imgs; p.HP = cd.hp; p.HR = cd.th + 2; p.HC = cd.tw + 2;
+    p.tiles_y = (re + cd.th - 1) / cd.th; p.tiles_x = (ce + cd.tw - 1) / cd.tw;
+    return cd.mt == 2 ? launch_conv3x3_cfg<T, 1, 1, 8, false, 2, false, 4>(p, L, st) : launch_conv3x3_cfg<T, 1, 1, 8, false, 1, false, 4>(p, L, st);
+  }
   // one tile shape for all classes, picked on the largest (even, even) class: the largest tile that still gives the launch 256 tiles
   static const int order[4] = {3, 1, 2, 0};
   const int rows_of[4] = {re, re, ro, ro}, cols_of[4] = {ce, co, ce, co};   // by class id (py, px) = (id >> 1, id & 1)
