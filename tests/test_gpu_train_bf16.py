@@ -345,3 +345,23 @@ def test_shape_sweep_forward_backward(dev, arch, B, P):
     for k in ("fc.weight", "fc.bias"):
         e = float((dict(m.named_parameters())[k].grad.cpu() - want[k].grad).norm() / (want[k].grad.norm() + 1e-30))
         assert e <= 0.15, (k, e)
+    # every gradient tensor against the emulation with the ENGINE's ReLU patterns imposed (the gate of test_forward_backward_vs_oracles,
+    # here at the sweep's shapes: 7 x 7 and 5 x 5 maps, 64-pixel-wide wgrad rows)
+    shapes = {}
+    hooks = [mod.register_forward_hook(lambda _m, _i, o, name=name: shapes.__setitem__(name, tuple(o.shape)))
+             for name, mod in ref.named_modules() if isinstance(mod, torch.nn.Conv2d)]
+    with torch.no_grad():
+        ref(x)
+    for h in hooks:
+        h.remove()
+    masks = {name: _act(m, name, 1, shp, dev) > 0 for name, shp in shapes.items() if "downsample" not in name}
+    emu2 = copy.deepcopy(ref)
+    emu2.zero_grad()
+    F.cross_entropy(forward_bf16(emu2, x, None, masks), y).backward()
+    want2 = {k: p.grad for k, p in emu2.named_parameters()}
+    bad = {}
+    for k, p in m.named_parameters():
+        e = float((p.grad.cpu() - want2[k]).norm() / (want2[k].norm() + 1e-30))
+        if e > 8e-2:
+            bad[k] = e
+    assert not bad, bad
