@@ -44,9 +44,22 @@ def init_from_env():
     return dist.get_rank(), dist.get_world_size(), dev_index, True
 
 
-def finalize(owned: bool) -> None:
+def finalize(owned: bool, ok: bool = True) -> None:
+    """End of a per-rank program.  Success: barrier, then destroy the group.  `ok=False` (the rank is leaving through an
+    exception): NO collective -- its peers sit in some other collective (a bucket all-reduce, the all-gather), a barrier here
+    would mismatch with it and block until the backend's timeout, hiding the exception; the process exits non-zero instead and
+    `torch.distributed.run` kills the other ranks."""
     import torch.distributed as dist
 
-    if owned and dist.is_initialized():
+    if not (owned and dist.is_initialized()):
+        return
+    if ok:
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        try:   # release the communicator without synchronising with anyone; never mask the original exception
+            abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
+            if abort is not None and dist.get_backend() == "nccl":
+                abort()
+        except Exception:
+            pass

@@ -148,7 +148,7 @@ def exchange_logits(local: torch.Tensor, n_unique: int, group=None) -> torch.Ten
     gathered = torch.empty((world * per_rank, local.shape[1]), dtype=local.dtype, device=local.device)
     try:
         dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
-    except (RuntimeError, NotImplementedError):  # backends without the flat form
+    except NotImplementedError:  # a backend without the flat form; a real RCCL failure (RuntimeError) must surface, not be retried
         parts = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(parts, local.contiguous(), group=group)
         gathered = torch.cat(parts)
@@ -184,7 +184,10 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     P = sampler.patch_size
     origins = sampler.origins                      # padded, reference order
     n_unique, n_padded = sampler.n_tiles, len(origins)
-    mb = micro_batch or 4096   # tiles per kernel launch (independent of the sampler's batch size; the library's maximum)
+    # tiles per kernel launch (independent of the sampler's batch size).  bf16: 4 096, the library's maximum (a 64 x 64 x 64-channel
+    # map of 4 096 tiles is 2 GiB).  float32: 1 024 -- the same map would be 4 GiB per tensor at 4 096 tiles, past the 32-bit byte
+    # offsets of the conv schedule tables (the library refuses it)
+    mb = micro_batch or (4096 if getattr(model, "compute_dtype", "f32") == "bf16" else 1024)
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
@@ -356,6 +359,7 @@ def main(argv=None, model=None):
     args = ap.parse_args(argv)
 
     rank, world, _dev_index, owned = init_from_env()   # binds the rank's GPU before any other GPU call
+    ok = False
     try:
         import torch.distributed as dist
         device = utils.get_device()
@@ -395,9 +399,10 @@ def main(argv=None, model=None):
             perform_and_save_visualizations(src, anno_dsc, pred, out_dir=Path(args.out_dir), stem=stem, device=device)
         if world > 1:
             dist.barrier()
+        ok = True
         return pred
     finally:
-        finalize(owned)
+        finalize(owned, ok)   # a failing rank leaves without a barrier (distributed.finalize)
 
 
 if __name__ == "__main__":

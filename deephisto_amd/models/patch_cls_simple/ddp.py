@@ -44,6 +44,42 @@ def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+def broadcast_state_(model, group=None, src: int = 0, buffers_only: bool = False) -> None:
+    """Rank `src`'s parameters and buffers (or the buffers alone: BN running statistics and batch counters) to every rank of
+    `group`, the broadcast torch DDP does in its constructor (and, for buffers, before every forward).  The models here are
+    initialised independently per rank (unseeded `kaiming_normal_`, torchvision's scheme): without this step the replicas
+    would average gradients taken at different points and never become identical.  One flat float32 collective for the
+    floating-point tensors and one int64 collective for the counters; the result goes back through `load_state_dict`, so
+    the native engines see it like any loaded checkpoint."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return
+    sd = model.state_dict()
+    if buffers_only:
+        keep = {n for n, _ in model.named_buffers()}
+        sd = {k: v for k, v in sd.items() if k in keep}
+    if not sd:
+        return
+    on_gpu = dist.get_backend(group) == "nccl"
+    fl = [k for k, v in sd.items() if v.is_floating_point()]
+    it = [k for k, v in sd.items() if not v.is_floating_point()]
+    for keys, dtype in ((fl, torch.float32), (it, torch.int64)):
+        if not keys:
+            continue
+        flat = torch.cat([sd[k].detach().to(dtype).reshape(-1) for k in keys])
+        home = flat.device
+        if on_gpu and not flat.is_cuda:
+            flat = flat.cuda()
+        dist.broadcast(flat, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+        flat, off = flat.to(home), 0
+        for k in keys:
+            n = sd[k].numel()
+            sd[k] = flat[off:off + n].reshape(sd[k].shape).to(sd[k].dtype)
+            off += n
+    model.load_state_dict(sd, strict=not buffers_only)
+
+
 class BucketReducer:
     """Asynchronous per-bucket all-reduce of slices of one flat gradient tensor.
 

@@ -30,6 +30,7 @@ from pathlib import Path
 import torch
 
 from . import utils
+from .ddp import broadcast_state_
 from .model import ce_loss, get_model
 from ...patch_samplers.region_samplers import (AnnoRegionRndSampler, RectRegionRndSampler, extract_and_save_subset,
                                                synthetic_regions)
@@ -192,6 +193,8 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print, model=
     if model is None:
         model = get_model(cfg["model"]["n_classes"], cfg.get("runtime", {}).get("compute_dtype", "f32"),
                           arch=cfg["model"].get("arch", "resnet18")).to(device)
+    if world > 1:   # every rank initialised its own weights: start all replicas from rank 0's (torch DDP's constructor broadcast)
+        broadcast_state_(model)
     sched = _PlateauLR(cfg["training"]["lr"])
     history = {"train_loss": [], "train_acc": [], "val_loss": [], "val_acc": [], "lr": [], "test_loss": [], "test_acc": []}
     best_val_acc = 0.0
@@ -215,6 +218,8 @@ def train(cfg, sampler=None, epochs=None, steps_per_epoch=200, log=print, model=
         log(f"Epoch {epoch + 1}/{n_epochs}  Train Loss: {train_loss:.4f}, Train Acc: {train_acc:.4f}")
 
         # validation: same sampler, same augmentations, eval-mode BN, no update (train.py:190-236)
+        if world > 1:   # per-rank batch statistics: validation, the checkpoint and the next epoch use rank 0's running statistics
+            broadcast_state_(model, buffers_only=True)
         model.eval()
         val_steps = cfg["training"]["val_steps"]
         vloss = torch.zeros((), device=device)
@@ -273,6 +278,7 @@ def main(argv=None):
     # one process per GPU under torch.distributed.run: bind the rank's GPU and join the RCCL group before any other GPU call
     from ...distributed import finalize, init_from_env
     rank, world, _dev, owned = init_from_env()
+    ok = False
     try:
         if args.extract_test and rank == 0:
             if Path(cfg["dataset"]["folder"]).exists():
@@ -283,9 +289,11 @@ def main(argv=None):
         if world > 1:
             import torch.distributed as dist
             dist.barrier()   # the test folder exists before any rank opens it
-        return train(cfg, epochs=args.epochs, steps_per_epoch=args.steps_per_epoch)
+        out = train(cfg, epochs=args.epochs, steps_per_epoch=args.steps_per_epoch)
+        ok = True
+        return out
     finally:
-        finalize(owned)
+        finalize(owned, ok)   # a failing rank leaves without a barrier: the launcher tears the job down
 
 
 if __name__ == "__main__":

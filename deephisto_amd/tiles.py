@@ -104,24 +104,31 @@ class PinnedUploader:
 
     def __init__(self, device, depth: int = 4):
         self.device, self.depth = torch.device(device), depth
-        self._slots: dict = {}
+        self._slots: dict = {}   # dtype -> [[pinned byte buffer, event of its last copy] x depth]
         self._next: dict = {}
 
     def upload(self, arr: "np.ndarray") -> torch.Tensor:
         import numpy as np
 
         arr = np.ascontiguousarray(arr)
-        key = (arr.dtype.str, arr.shape)
+        # one ring per DTYPE, each slot sized to the largest request so far (grown geometrically): arrays whose length changes
+        # from batch to batch (per-slide selections of the region samplers) reuse the same pinned memory instead of pinning
+        # `depth` new buffers per distinct shape -- pin_memory() is a synchronous hipHostMalloc, the stall this class avoids
+        key = arr.dtype.str
         if key not in self._slots:
-            self._slots[key] = [[torch.from_numpy(np.empty_like(arr)).pin_memory(), None] for _ in range(self.depth)]
+            self._slots[key] = [[None, None] for _ in range(self.depth)]
             self._next[key] = 0
         k = self._next[key]
         self._next[key] = (k + 1) % self.depth
         slot = self._slots[key][k]
         if slot[1] is not None:
             slot[1].synchronize()
-        slot[0].numpy()[...] = arr
-        out = slot[0].to(self.device, non_blocking=True)
+        n = arr.size
+        if slot[0] is None or slot[0].numel() < n:
+            cap = max(n, 2 * (slot[0].numel() if slot[0] is not None else 0), 64)
+            slot[0] = torch.from_numpy(np.empty(cap, dtype=arr.dtype)).pin_memory()
+        slot[0].numpy()[:n] = arr.reshape(-1)
+        out = slot[0][:n].to(self.device, non_blocking=True).reshape(arr.shape)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         slot[1] = ev

@@ -27,8 +27,8 @@ class StubModel(nn.Module):
 
     def __init__(self):
         super().__init__()
-        torch.manual_seed(0)
-        self.fc = nn.Linear(12, 5)
+        torch.manual_seed(77 + int(os.environ["RANK"]))   # every rank starts from its OWN weights, like the HIP models' unseeded init:
+        self.fc = nn.Linear(12, 5)                         # train() must broadcast rank 0's before the first step
 
     def forward(self, x):
         return self.fc(x.flatten(1))
@@ -52,7 +52,9 @@ class StubSampler:
         report["sampler_seed"] = seed
 
     def device_batches(self, bs, n, flips=True):
-        for _ in range(n):
+        for k in range(n):
+            if os.environ.get("DH_STUB_FAIL_RANK") == os.environ["RANK"] and k == 1:
+                raise RuntimeError("stub sampler failure on one rank")   # its peer is inside the next step's all-reduce
             yield torch.rand(bs, 3, 2, 2, generator=self.g), torch.randint(0, 5, (bs,), generator=self.g), None
 
 
@@ -61,6 +63,7 @@ T.ce_loss = lambda logits, labels: nn.functional.cross_entropy(logits, labels)  
 T._synthetic_sampler = lambda cfg, device: StubSampler(T._rank_world()[0])
 _real_train = T.train
 model = StubModel()
+report["initial_weights"] = model.fc.weight.detach().flatten().tolist()
 T.train = lambda cfg, **kw: _real_train(cfg, model=model, **kw)
 
 cfg = {"dataset": {"folder": "/nonexistent", "layer": 1, "patch_size": 2, "patches_from_one_region": 1},

@@ -30,12 +30,27 @@ def test_train_main_two_gloo_ranks(tmp_path):
         assert rep["rank_env"] == k and rep["sampler_seed"] == k          # every rank draws its own stream of patches
         assert not rep["initialized_before_main"] and rep["group_up_in_train_step"]
         assert not rep["initialized_after_main"]                           # destroy_process_group at exit
-    assert reps[0]["weights"] == reps[1]["weights"]                        # replicas stay identical
+    assert reps[0]["initial_weights"] != reps[1]["initial_weights"]        # per-rank initialisation ...
+    assert reps[0]["weights"] == reps[1]["weights"]                        # ... rank 0's is broadcast: replicas identical bit for bit
     assert reps[0]["history"] == reps[1]["history"]                        # metrics averaged: same LR / checkpoint decisions
     assert len(reps[0]["history"]["val_loss"]) == 2
     sd = torch.load(tmp_path / "best_model.pth", weights_only=True)        # written by rank 0 only
     assert set(sd) == {"fc.weight", "fc.bias"}
     assert "Using device" in r.stdout and r.stdout.count("Using device") == 1   # rank 0 reports
+
+
+def test_failing_rank_exits_without_a_barrier(tmp_path):
+    """a rank leaving through an exception must not enter a barrier its peers will never match -- the job ends
+    non-zero with the original exception on stderr, long before the backend's collective timeout (minutes)."""
+    import time
+    env = dict(os.environ, DH_DIST_BACKEND="gloo", OMP_NUM_THREADS="1", DH_STUB_FAIL_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(REPO / "tests" / "helpers" / "ddp_cli_stub.py"), str(tmp_path)]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert "stub sampler failure on one rank" in r.stderr
+    assert time.time() - t0 < 120
 
 
 def test_init_from_env_single_process_is_a_noop(monkeypatch):
