@@ -305,6 +305,35 @@ def cpu_train_baseline(steps: int, arch: str = "resnet18") -> dict:
             "sample": f"{steps} steps of batch 64 x 224^2, torch-CPU fp32 {arch} eager + Adam, {threads} threads, {dt:.1f} s"}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks as a CHILD `torch.distributed.run` job
+    (one process per GPU, rendezvous on 127.0.0.1) before this process has touched a GPU, relay rank 0's JSON line on stdout
+    and return the job's exit code.  (Never an exec: a process that may already have initialised the GPU must not be replaced.)"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:            # ranks other than 0 print nothing on stdout; keep the last JSON object line
+        if out.lstrip().startswith("{"):
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return rc if rc != 0 or line is not None else 1
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -312,7 +341,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
+            sys.exit(self_launch(args.gpus))   # `python bench.py --gpus N`: become the launcher, before any GPU call
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
@@ -349,15 +378,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    exchange_events: list = []   # (start, end) HIP events around every all-gather of the timed region (world > 1)
+
     def timed_predict(mdl, steps, warmup, micro_batch=None):
         """(elapsed seconds for `steps` whole slides, dominant-kernel ms / flops / samples over the timed region, class map)"""
         def step():
-            return predict_full_patched(smp, mdl, 5, downscale=args.downscale, micro_batch=micro_batch or args.micro_batch, streams=args.streams)
+            return predict_full_patched(smp, mdl, 5, downscale=args.downscale, micro_batch=micro_batch or args.micro_batch, streams=args.streams,
+                                        timing=exchange_events)
         for _ in range(warmup):
             step()
         fence()
         # live timing of the dominant kernel over the timed region (every 4th launch sampled)
         check(lib().dh_profile_start(4, 65536), "dh_profile_start")
+        exchange_events.clear()
         t0 = time.perf_counter()
         for _ in range(steps):
             cm = step()
@@ -375,14 +408,36 @@ def main():
     assert cmap.shape == (side // args.downscale, side // args.downscale)
 
     # configs[4] under torch.distributed: ResNet-50 bf16 data-parallel steps (every rank takes part; reported by rank 0)
+    allgather_ms = None
+    if world > 1 and exchange_events:
+        allgather_ms = sum(a.elapsed_time(b) for a, b in exchange_events) / len(exchange_events)
     train_ddp = None
     if world > 1 and args.train_steps > 0 and not args.no_extra_legs:
         try:
             del slide, smp
             torch.cuda.empty_cache()
+            # the same per-rank step three ways: gradients exchanged in float32 (default wire), in bf16 (half the bytes per xGMI
+            # link), and not exchanged at all -- the difference is what the bucketed, overlapped all-reduce leaves exposed
+            os.environ["DH_DDP_WIRE"] = "f32"
             train_ddp = train_leg(dev, args.train_steps, "resnet50", "bf16", group=dist.group.WORLD)
+            os.environ["DH_DDP_WIRE"] = "bf16"
+            leg_bf16 = train_leg(dev, args.train_steps, "resnet50", "bf16", group=dist.group.WORLD)
+            os.environ["DH_DDP_WIRE"] = "f32"
+            solo = [dist.new_group([r]) for r in range(world)][rank]   # a group of this rank alone: train_step sees world = 1, no exchange
+            local = train_leg(dev, args.train_steps, "resnet50", "bf16", group=solo)
+            lm = torch.tensor([local["ms_per_step"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(lm, op=dist.ReduceOp.MAX)     # the slowest rank's un-exchanged step
+            train_ddp["local_step_ms"] = float(lm.item())
+            train_ddp["allreduce_exposed_ms"] = train_ddp["ms_per_step"] - float(lm.item())
+            train_ddp["wire_bf16"] = {"steps_per_s": leg_bf16["steps_per_s"], "ms_per_step": leg_bf16["ms_per_step"],
+                                      "allreduce_exposed_ms": leg_bf16["ms_per_step"] - float(lm.item()),
+                                      "parallelism": leg_bf16["config"].get("parallelism")}
         except Exception as e:   # never costs the headline number
-            train_ddp = {"error": f"{type(e).__name__}: {e}"[:400]}
+            err = {"error": f"{type(e).__name__}: {e}"[:400]}
+            train_ddp = dict(train_ddp, **err) if isinstance(train_ddp, dict) else err
+    if world > 1:   # every collective is done: the ranks part here, rank 0 goes on to the CPU baseline alone
+        dist.barrier()
+        dist.destroy_process_group()
 
     if rank == 0:
         value = args.steps * n_tiles / elapsed
@@ -445,18 +500,17 @@ def main():
             out["train_bf16"] = train_leg(dev, args.train_steps, "resnet18", "bf16")   # the same network on the bf16 engine (f32 masters)
             out["train_r50"] = train_leg(dev, args.train_steps, "resnet50", "bf16")
         if world > 1:
+            out["allgather_ms"] = allgather_ms   # HIP-event time of the ONE RCCL all-gather of per-tile logits, mean per slide (rank 0)
             out["train_ddp"] = train_ddp
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-            if not args.no_extra_legs:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)   # rank 0, after the group is gone
+            if not args.no_extra_legs and world == 1:
                 out["cpu_baselines"] = {"sampler_generator_torch": cpu_sampler_baseline(args, 4.0),
                                         "train_step_resnet18_f32": cpu_train_baseline(2),
                                         "train_step_resnet50_f32": cpu_train_baseline(2, "resnet50")}
-        elif world > 1:
+        else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1216,6 +1216,11 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
   const int H2 = (H1 + 2 - 3) / 2 + 1;      // pool out
   const size_t stem_bytes = (size_t)B * H1 * H1 * 64 * esz;
   const size_t act_bytes = (size_t)B * H2 * H2 * 64 * esz;  // largest post-pool activation
+  // BEFORE any launch: the conv schedule tables carry window byte offsets as 32-bit words (the stem and pool kernels index with
+  // 64 bits) -- a launch whose largest conv input does not fit is refused here, not half-way through the network
+  DH_REQUIRE(act_bytes < ((size_t)1 << 32),
+             "resnet18 forward: %d tiles of %d x %d in %s make an activation larger than 4 GiB: use fewer tiles per launch", B, P, P,
+             sizeof(T) == 2 ? "bf16" : "float32");
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t need = al(stem_bytes) + 3 * al(act_bytes);
   if (need > net->ws_bytes) {

@@ -161,7 +161,7 @@ def exchange_logits(local: torch.Tensor, n_unique: int, group=None) -> torch.Ten
 
 def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_classes: int,
                          downscale: int = 16, micro_batch: int | None = None, group=None,
-                         return_logits: bool = False, streams: int = 2, dedupe_padding: bool = False):
+                         return_logits: bool = False, streams: int = 2, dedupe_padding: bool = False, timing: list | None = None):
     """Device-resident whole-slide prediction (rows a1-a8 end to end).
 
     Single process: every tile (padding duplicates included) goes through the fused
@@ -174,6 +174,7 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     canvas equals the single-GPU / reference result.
     `dedupe_padding=True` leaves the padding duplicates of the corner tile out of the accumulation (the reference adds them,
     predict_full_patched.py:49-54, which is the default here).
+    `timing`: a list that receives one (start, end) pair of HIP events around the all-gather (bench.py's `allgather_ms`).
     Returns int64[h//d, w//d] on the device (and the float32[n_padded, n_cls] logits).
     """
     import torch.distributed as dist
@@ -216,7 +217,14 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
               "dh_resnet18_forward_tiles")
     for st in lanes[1:]:
         main.wait_stream(st)
-    logits_unique = exchange_logits(local, n_unique, group) if distributed else local[:n_unique]
+    if distributed and timing is not None and local.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(main)
+        logits_unique = exchange_logits(local, n_unique, group)
+        ev[1].record(main)
+        timing.append(ev)
+    else:
+        logits_unique = exchange_logits(local, n_unique, group) if distributed else local[:n_unique]
     pad = n_padded - n_unique
     logits = torch.cat([logits_unique, logits_unique[-1:].expand(pad, -1)]) if pad else logits_unique
     if dedupe_padding:
