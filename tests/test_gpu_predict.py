@@ -262,7 +262,7 @@ def test_default_micro_batch_per_dtype_matches_1024(dev):
     """the library default micro-batch is 4 096 tiles for bf16 and 1 024 for float32 (a float32 64 x 64 x 64 map of
     4 096 tiles is 2^32 bytes: past the 32-bit byte offsets of the conv schedule, which the library refuses).  A slide of
     4 356 tiles (two launches of 2 178 at the bf16 default, five at 1 024): default == explicit 1 024, bit for bit, both dtypes;
-    and an explicit float32 micro-batch of 4 096 fails loudly instead of wrapping."""
+    and a float32 launch of 4 096 tiles fails loudly instead of wrapping."""
     from deephisto_amd import tiles
     from deephisto_amd.examples.predict_full_patched import predict_full_patched
     from deephisto_amd.models.patch_cls_simple.model import get_model
@@ -281,8 +281,8 @@ def test_default_micro_batch_per_dtype_matches_1024(dev):
         assert torch.equal(lg_a, lg_b) and torch.equal(cm_a, cm_b), dtype
         assert bool(torch.isfinite(lg_a).all())
         if dtype == "f32":
-            with pytest.raises(RuntimeError, match="4 Gi|larger|tiles"):
-                predict_full_patched(smp, model, 5, downscale=16, micro_batch=4096)
+            with pytest.raises(RuntimeError, match="larger than 4 GiB"):   # one launch of 4 096 float32 tiles: refused before any kernel
+                model.forward_tiles(slide, torch.from_numpy(np.ascontiguousarray(smp.origins[:4096])).to(dev), P)
         del model
         torch.cuda.empty_cache()
 
