@@ -24,7 +24,7 @@ _i32, _i64, _u32 = C.c_int32, C.c_int64, C.c_uint32
 BUCKET_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int64, C.c_int64, C.c_void_p)   # dh_bucket_cb
 _p = C.c_void_p
 
-# name -> (restype, argtypes); must list every symbol of include/deephisto_hip.h
+# name -> (restype, argtypes); must list every symbol of include/deephisto_hip.h (the drop-in boundary, ABI version 1)
 SIGNATURES = {
     "dh_abi_version": (C.c_int, []),
     "dh_last_error": (C.c_char_p, []),
@@ -69,6 +69,14 @@ SIGNATURES = {
     "dh_grad_pack_bf16": (C.c_int, [_p, _p, _i64, _p]),
     "dh_grad_unpack_bf16": (C.c_int, [_p, _p, _i64, C.c_float, _p]),
     "dh_train2_backward_adam": (C.c_int, [_p, _p, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
+    "dh_profile_start": (C.c_int, [_i32, _i32]),
+    "dh_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+}
+
+
+# test hooks declared in include/deephisto_hip_debug.h: exported by the same library, NOT part of the versioned boundary
+# (signatures follow the kernels' internals); only tests/ and tools/ call them
+DEBUG_SIGNATURES = {
     "dh_train2_debug_act": (C.c_int, [_p, C.c_char_p, _i32, _p, _i64, _p]),
     "dh_debug_gemm1x1_bf16": (C.c_int, [_p, _p, _p, _p, _i64] + [_i32] * 8 + [_p]),
     "dh_debug_gemm1x1_fused_bf16": (C.c_int, [_p] * 7 + [_i64] + [_i32] * 8 + [_p]),
@@ -90,8 +98,6 @@ SIGNATURES = {
     "dh_debug_maxpool_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_bn_pool_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_stamps": (C.c_int, [_i32, _p]),
-    "dh_profile_start": (C.c_int, [_i32, _i32]),
-    "dh_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
 }
 
 
@@ -111,7 +117,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -m deephisto_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
         h = C.CDLL(str(LIB_PATH))
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
             fn = getattr(h, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
         _lib = h

@@ -1,0 +1,193 @@
+// conv3_tables_host.h -- HOST-ONLY integer code behind the 3x3 convolution kernel (conv3x3.inc): tile-shape choice, per-thread
+// geometry, per-tile schedule and mask tables.  Every LDS-DMA source address and every output address of the kernel comes out of
+// these tables, so the file is kept free of HIP: resnet_kernels.hip includes it for the product, and
+// tests/host/conv3_tables_sweep.cpp compiles it with `g++ -fsanitize=address,undefined` and sweeps the shapes the engines use,
+// asserting that every offset lies inside its tensor and fits its integer type (tests/test_conv_tables_host.py, CPU only).
+//
+// `P` is any struct with the geometry fields of Conv3Params (TH, TW, IMGS, HR, HC, HP, HPH, Hi, Wi, Cin, B, tiles_y, tiles_x,
+// n_win_instr, in_px_bytes, Ho, Wo, Cout, out_px, out_cb, o_img, o_row, o_px, o_base, ntiles, iters).
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <map>
+#include <vector>
+
+namespace dh_conv3 {
+
+constexpr int kChunkBytes = 64;   // channel bytes of one pixel staged per pass (CHUNK_BYTES)
+
+struct TileDesc { int x, y, z, w; };   // {cout block | valid << 16 | mask row << 20, window byte offset, output element offset, 0}
+
+struct HostTables {
+  std::vector<int> lane;        // [threads][2 NT + MAXJ] = {out_rel[NT], base_lin[NT], rel_off[MAXJ]}
+  std::vector<TileDesc> tile;   // [iters][grid]
+  std::vector<unsigned> mask;   // [mask rows][threads]: bits 0..MAXJ-1 window piece j inside the image, bit 16 + nt: pixel nt exists
+  int grid = 0, threads = 0, lane_stride = 0, mask_rows = 0;
+  bool xcd_group = false;
+};
+
+template <int STRIDE, int NT, int WAVES>
+constexpr int max_window_pieces() { return (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4); }
+
+// Tile shapes of the stride-1 kernel from the largest down: {TH, TW, IMGS, HP, variant}; variant 0: NT=2 MT=2 (512 pixels),
+// 1: NT=1 MT=2 (256), 2: NT=1 MT=1 (128).  The first candidate that gives the launch `min_tiles` tiles wins, else the smallest.
+struct Cand { int th, tw, imgs, hp, variant; };
+inline int stride1_candidates(int Ho, int Wo, Cand (&c)[4]) {
+  int nc = 0;
+  if (Wo > 16) {
+    // 16x32 or 8x64 output pixels, whichever wastes fewer tile slots (56x56: 77 % vs 88 % useful)
+    const int slots_a = ((Ho + 15) / 16) * ((Wo + 31) / 32), slots_b = ((Ho + 7) / 8) * ((Wo + 63) / 64);
+    if (slots_b < slots_a) c[nc++] = {8, 64, 1, 66, 0};
+    else c[nc++] = {16, 32, 1, 34, 0};
+    c[nc++] = {16, 16, 1, 18, 1};
+  } else if (Wo > 8) {
+    c[nc++] = {16, 16, 2, 18, 0};
+    c[nc++] = {16, 16, 1, 18, 1};
+    c[nc++] = {8, 8, 2, 12, 2};
+  } else {
+    c[nc++] = {8, 8, 4, 12, 1};   // pitch 12: see lane_pos
+    c[nc++] = {8, 8, 2, 12, 2};
+  }
+  return nc;
+}
+inline int tiles_of(const Cand& c, int B, int Ho, int Wo, int cout) {
+  return Ho > 0 && Wo > 0 ? ((B + c.imgs - 1) / c.imgs) * ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw) * (cout / 64) : 0;
+}
+inline Cand pick_stride1(int B, int Ho, int Wo, int cout, int min_tiles) {
+  Cand c[4];
+  const int nc = stride1_candidates(Ho, Wo, c);
+  for (int i = 0; i < nc; ++i)
+    if (tiles_of(c[i], B, Ho, Wo, cout) >= min_tiles) return c[i];
+  return c[nc - 1];
+}
+// stride-2 kernel: 128-pixel tiles (8 x 16, or 8 x 8 x 2 images); window = (2 TH + 1) x (2 TW + 1), columns split by parity
+template <class P> inline void set_stride2_geometry(P& p, int Ho, int Wo) {
+  if (Wo > 8) { p.TH = 8; p.TW = 16; p.IMGS = 1; }
+  else { p.TH = 8; p.TW = 8; p.IMGS = 2; }
+  p.HR = 2 * p.TH + 1; p.HC = 2 * p.TW + 1; p.HPH = p.TW + 1; p.HP = 2 * p.HPH;
+  p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
+}
+template <class P> inline void set_stride1_geometry(P& p, const Cand& c, int Ho, int Wo) {
+  p.TH = c.th; p.TW = c.tw; p.IMGS = c.imgs; p.HP = c.hp; p.HPH = 0;
+  p.HR = p.TH + 2; p.HC = p.TW + 2;
+  p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
+}
+
+// Returns nullptr, or the reason the shape cannot be scheduled.  `grid_override` > 0: the launch's share of a merged launch.
+template <int STRIDE, int NT, int WAVES, int ESZ, int MT, class P>
+const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out) {
+  constexpr int MAXJ = max_window_pieces<STRIDE, NT, WAVES>();
+  const int threads = WAVES * 64, stride = 2 * NT + MAXJ;
+  std::vector<int>& lane = out->lane;
+  lane.assign((size_t)threads * stride, 0);
+  // per-thread geometry kept for the mask rows below: output pixel (ty, tx, img) per n-tile, window piece (hy, hx, img, live)
+  std::vector<std::array<int, 3>> pix((size_t)threads * NT);
+  std::vector<std::array<int, 4>> win((size_t)threads * MAXJ);
+  const int64_t img_in_bytes = (int64_t)p.Hi * p.Wi * p.Cin * ESZ;
+  for (int tid = 0; tid < threads; ++tid) {
+    const int l = tid & 63, wave = tid >> 6;
+    int* row = &lane[(size_t)tid * stride];
+    // Lane -> pixel of the n-tile.  A ds_read_b128 is served in two groups of 16 lanes per half-wave,
+    // A = {0-3, 12-15, 20-27} and B = {4-11, 16-19, 28-31}; the swizzled window image is conflict-free when the 16
+    // pixels of a group have 16 different (linear index mod 16).  Rows of 32 pixels satisfy that in lane order;
+    // 16- and 8-pixel rows do when group A takes rows {0} / {0, 2} and group B rows {1} / {1, 3} (row pitches are
+    // chosen so that those row pairs cover disjoint residues).
+    auto lane_pos = [&](int ll) {
+      if (p.TW >= 32) return ll;
+      const bool in_a = ll < 4 || (ll >= 12 && ll < 16) || (ll >= 20 && ll < 28);
+      const int rank = in_a ? (ll < 4 ? ll : ll < 16 ? ll - 8 : ll - 12) : (ll < 12 ? ll - 4 : ll < 20 ? ll - 8 : ll - 16);
+      if (p.TW == 16) return (in_a ? 0 : 16) + rank;
+      return (in_a ? 0 : 8) + (rank < 8 ? rank : rank + 8);   // TW == 8: A -> rows 0, 2; B -> rows 1, 3
+    };
+    for (int nt = 0; nt < NT; ++nt) {
+      const int pidx = ((MT == 2 ? wave : wave >> 1) * NT + nt) * 32 + lane_pos(l & 31);   // MT == 1: wave pairs share pixels
+      const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
+      const int ty = rem / p.TW, tx = rem % p.TW;
+      pix[(size_t)tid * NT + nt] = {ty, tx, img};
+      const int64_t orel = (int64_t)img * p.o_img + (int64_t)ty * p.o_row + (int64_t)tx * p.o_px;   // relative to the tile's origin
+      if (orel < 0 || orel > INT32_MAX) return "conv3x3: per-lane output offset does not fit 31 bits";
+      row[nt] = (int)orel;
+      row[NT + nt] = (img * p.HR + ty * STRIDE) * p.HP + tx;
+    }
+    // window DMA: instruction i = wave + WAVES*j fills LDS pixels 16i..16i+15; lane l fills LDS slot (l&3)
+    // of pixel 16i + l/4 with GLOBAL slot (l&3) ^ swizzle(pixel)
+    for (int j = 0; j < MAXJ; ++j) {
+      const int i = wave + WAVES * j;
+      const int px = i * 16 + (l >> 2);
+      const int img = px / (p.HR * p.HP), r = px % (p.HR * p.HP);
+      const int hy = r / p.HP, c = r % p.HP;
+      int hx = c;
+      if (STRIDE == 2) hx = 2 * (c % p.HPH) + c / p.HPH;
+      const bool live = i < p.n_win_instr && img < p.IMGS && hx < p.HC;
+      const int g = (l & 3) ^ ((px >> 2) & 3);
+      const int64_t roff = (int64_t)img * img_in_bytes + ((int64_t)(hy - 1) * p.Wi + hx - 1) * p.in_px_bytes + g * 16;
+      if (live && (roff < INT32_MIN || roff > INT32_MAX)) return "conv3x3: per-lane window offset does not fit 32 bits";
+      row[2 * NT + j] = live ? (int)roff : 0;   // (dead pieces are never dereferenced: their mask bit is clear in every row)
+      win[(size_t)tid * MAXJ + j] = {hy, hx, img, live ? 1 : 0};
+    }
+  }
+  // Mask rows: one per distinct (oy0, ox0, images left in the group): bit j = window piece j of the thread lies inside the
+  // image, bit 16 + nt = output pixel nt exists.  The kernel fetches its word of the row one tile ahead.
+  std::map<std::array<int, 3>, int> mask_row;
+  std::vector<unsigned>& mask = out->mask;
+  mask.clear();
+  auto mask_row_of = [&](int img0, int oy0, int ox0) {
+    const std::array<int, 3> mk = {oy0, ox0, std::min(p.IMGS, std::max(0, p.B - img0))};
+    auto it = mask_row.find(mk);
+    if (it != mask_row.end()) return it->second;
+    const int r = (int)mask_row.size();
+    mask_row[mk] = r;
+    mask.resize((size_t)(r + 1) * threads);
+    for (int tid = 0; tid < threads; ++tid) {
+      unsigned m = 0;
+      for (int j = 0; j < MAXJ; ++j) {
+        const auto& w = win[(size_t)tid * MAXJ + j];
+        const int iy = oy0 * STRIDE + w[0] - 1, ix = ox0 * STRIDE + w[1] - 1;
+        if (w[3] && w[2] < mk[2] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) m |= 1u << j;
+      }
+      for (int nt = 0; nt < NT; ++nt) {
+        const auto& q = pix[(size_t)tid * NT + nt];
+        if (q[2] < mk[2] && oy0 + q[0] < p.Ho && ox0 + q[1] < p.Wo) m |= 1u << (16 + nt);
+      }
+      mask[(size_t)r * threads + tid] = m;
+    }
+    return r;
+  };
+  // Schedule [iters][grid]: which (pixel tile, cout block) a workgroup takes in which iteration.  Workgroups are
+  // dispatched round-robin over the 8 XCDs (workgroup w -> XCD w % 8), each with its own 4 MiB L2.  The ncb cout
+  // blocks of a pixel tile go to ncb workgroups of ONE XCD in the same iteration (`xcd_group`), so the staged window
+  // is fetched into that L2 once and hit ncb - 1 times; measured -8 % (layer 2) ... -16 % (stride-2 layers) against
+  // cout block = workgroup % ncb (one weight slice per XCD), also for the 512-channel layers whose 4.7 MB of weights
+  // no longer fit one L2 (they come from the Infinity Cache instead).
+  // Either way a workgroup keeps its cout block for all iterations (resident-weight variants rely on it).
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const int grid = grid_override > 0 ? grid_override : std::min(256, p.ntiles), n_pt = p.ntiles / ncb;   // (override: a share of a merged launch)
+  const bool xcd_group = ncb > 1 && grid == 256 && 32 % ncb == 0 && (int64_t)p.Cout * p.Cin * 9 * ESZ <= (1 << 23);
+  std::vector<TileDesc>& tile = out->tile;
+  tile.assign((size_t)p.iters * grid, TileDesc{0, 0, 0, 0});
+  for (int it = 0; it < p.iters; ++it)
+    for (int w = 0; w < grid; ++w) {
+      int cb, pt;
+      if (xcd_group) {
+        const int xcd = w % 8, slot = w / 8;
+        cb = slot % ncb;
+        pt = it * (grid / ncb) + (slot / ncb) * 8 + xcd;
+      } else {
+        const int T_ = it * grid + w;
+        cb = T_ % ncb; pt = T_ / ncb;
+      }
+      const int valid = pt < n_pt ? 1 : 0, t = pt % tiles_per_img;
+      const int img0 = valid ? (pt / tiles_per_img) * p.IMGS : 0, oy0 = (t / p.tiles_x) * p.TH, ox0 = (t % p.tiles_x) * p.TW;
+      const int mrow = mask_row_of(img0, oy0, ox0);
+      if (mrow >= 4096) return "conv3x3: too many distinct tile positions for the mask table";
+      const int64_t win_off = (int64_t)img0 * img_in_bytes + ((int64_t)(oy0 * STRIDE) * p.Wi + ox0 * STRIDE) * p.in_px_bytes;
+      const int64_t out_off = (int64_t)img0 * p.o_img + (int64_t)oy0 * p.o_row + (int64_t)ox0 * p.o_px + p.o_base + (int64_t)cb * p.out_cb;
+      if (win_off >= ((int64_t)1 << 32) || out_off >= ((int64_t)1 << 32)) return "conv3x3: tensor larger than 4 Gi elements / bytes";
+      tile[(size_t)it * grid + w] = TileDesc{cb | (valid << 16) | (mrow << 20), (int)(uint32_t)win_off, (int)(uint32_t)out_off, 0};
+    }
+  out->grid = grid; out->threads = threads; out->lane_stride = stride; out->mask_rows = (int)mask_row.size(); out->xcd_group = xcd_group;
+  return nullptr;
+}
+
+}  // namespace dh_conv3

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/deephisto_hip.h"
+#include "../../include/deephisto_hip_debug.h"   // test hooks: exported, unversioned
 
 namespace dh {
 

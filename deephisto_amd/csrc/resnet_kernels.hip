@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "dh_common.h"
+#include "conv3_tables_host.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -723,7 +724,6 @@ constexpr size_t CONV3_TABLE_CAP = 256;
 
 template <int STRIDE, int NT, int WAVES, int ESZ, int MT>
 int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out, int grid_override = 0) {
-  constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
   const std::vector<int> key = {current_device(), STRIDE, NT, WAVES, MT, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi,
                                 p.Cin, p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes, p.Ho, p.Wo, p.Cout, p.out_px,
                                 p.out_cb, (int)(p.o_img & 0x7FFFFFFF), (int)(p.o_img >> 31), p.o_row, p.o_px, p.o_base, grid_override, p.iters};
@@ -734,106 +734,12 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
     for (auto& kv : g_conv3_tables) { (void)hipFree(kv.second.lane); (void)hipFree(kv.second.tile); (void)hipFree(kv.second.mask); }
     g_conv3_tables.clear();
   }
-  const int threads = WAVES * 64, stride = 2 * NT + MAXJ;
-  std::vector<int> lane((size_t)threads * stride);
-  // per-thread geometry kept on the host for the mask rows below: output pixel (ty, tx, img) per n-tile, window piece (hy, hx, img, live)
-  std::vector<std::array<int, 3>> pix((size_t)threads * NT);
-  std::vector<std::array<int, 4>> win((size_t)threads * MAXJ);
-  for (int tid = 0; tid < threads; ++tid) {
-    const int l = tid & 63, wave = tid >> 6;
-    int* row = &lane[(size_t)tid * stride];
-    // Lane -> pixel of the n-tile.  A ds_read_b128 is served in two groups of 16 lanes per half-wave,
-    // A = {0-3, 12-15, 20-27} and B = {4-11, 16-19, 28-31}; the swizzled window image is conflict-free when the 16
-    // pixels of a group have 16 different (linear index mod 16).  Rows of 32 pixels satisfy that in lane order;
-    // 16- and 8-pixel rows do when group A takes rows {0} / {0, 2} and group B rows {1} / {1, 3} (row pitches are
-    // chosen so that those row pairs cover disjoint residues).
-    auto lane_pos = [&](int ll) {
-      if (p.TW >= 32) return ll;
-      const bool in_a = ll < 4 || (ll >= 12 && ll < 16) || (ll >= 20 && ll < 28);
-      const int rank = in_a ? (ll < 4 ? ll : ll < 16 ? ll - 8 : ll - 12) : (ll < 12 ? ll - 4 : ll < 20 ? ll - 8 : ll - 16);
-      if (p.TW == 16) return (in_a ? 0 : 16) + rank;
-      return (in_a ? 0 : 8) + (rank < 8 ? rank : rank + 8);   // TW == 8: A -> rows 0, 2; B -> rows 1, 3
-    };
-    for (int nt = 0; nt < NT; ++nt) {
-      const int pidx = ((MT == 2 ? wave : wave >> 1) * NT + nt) * 32 + lane_pos(l & 31);   // MT == 1: wave pairs share pixels
-      const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
-      const int ty = rem / p.TW, tx = rem % p.TW;
-      pix[(size_t)tid * NT + nt] = {ty, tx, img};
-      row[nt] = (int)(img * p.o_img + (int64_t)ty * p.o_row + (int64_t)tx * p.o_px);   // output element offset relative to the tile's origin
-      row[NT + nt] = (img * p.HR + ty * STRIDE) * p.HP + tx;
-    }
-    // window DMA: instruction i = wave + WAVES*j fills LDS pixels 16i..16i+15; lane l fills LDS slot (l&3)
-    // of pixel 16i + l/4 with GLOBAL slot (l&3) ^ swizzle(pixel)
-    for (int j = 0; j < MAXJ; ++j) {
-      const int i = wave + WAVES * j;
-      const int px = i * 16 + (l >> 2);
-      const int img = px / (p.HR * p.HP), r = px % (p.HR * p.HP);
-      const int hy = r / p.HP, c = r % p.HP;
-      int hx = c;
-      if (STRIDE == 2) hx = 2 * (c % p.HPH) + c / p.HPH;
-      const bool live = i < p.n_win_instr && img < p.IMGS && hx < p.HC;
-      const int g = (l & 3) ^ ((px >> 2) & 3);
-      row[2 * NT + j] = img * p.Hi * p.Wi * p.Cin * ESZ + ((hy - 1) * p.Wi + hx - 1) * p.in_px_bytes + g * 16;
-      win[(size_t)tid * MAXJ + j] = {hy, hx, img, live ? 1 : 0};
-    }
-  }
-  // Mask rows: one per distinct (oy0, ox0, images left in the group): bit j = window piece j of the thread lies inside the
-  // image, bit 16 + nt = output pixel nt exists.  The kernel fetches its word of the row one tile ahead.
-  std::map<std::array<int, 3>, int> mask_row;
-  std::vector<unsigned> mask;
-  auto mask_row_of = [&](int img0, int oy0, int ox0) {
-    const std::array<int, 3> mk = {oy0, ox0, std::min(p.IMGS, std::max(0, p.B - img0))};
-    auto it = mask_row.find(mk);
-    if (it != mask_row.end()) return it->second;
-    const int r = (int)mask_row.size();
-    mask_row[mk] = r;
-    mask.resize((size_t)(r + 1) * threads);
-    for (int tid = 0; tid < threads; ++tid) {
-      unsigned m = 0;
-      for (int j = 0; j < MAXJ; ++j) {
-        const auto& w = win[(size_t)tid * MAXJ + j];
-        const int iy = oy0 * STRIDE + w[0] - 1, ix = ox0 * STRIDE + w[1] - 1;
-        if (w[3] && w[2] < mk[2] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) m |= 1u << j;
-      }
-      for (int nt = 0; nt < NT; ++nt) {
-        const auto& q = pix[(size_t)tid * NT + nt];
-        if (q[2] < mk[2] && oy0 + q[0] < p.Ho && ox0 + q[1] < p.Wo) m |= 1u << (16 + nt);
-      }
-      mask[(size_t)r * threads + tid] = m;
-    }
-    return r;
-  };
-  // Schedule [iters][grid]: which (pixel tile, cout block) a workgroup takes in which iteration.  Workgroups are
-  // dispatched round-robin over the 8 XCDs (workgroup w -> XCD w % 8), each with its own 4 MiB L2.  The ncb cout
-  // blocks of a pixel tile go to ncb workgroups of ONE XCD in the same iteration (`xcd_group`), so the staged window
-  // is fetched into that L2 once and hit ncb - 1 times; measured -8 % (layer 2) ... -16 % (stride-2 layers) against
-  // cout block = workgroup % ncb (one weight slice per XCD), also for the 512-channel layers whose 4.7 MB of weights
-  // no longer fit one L2 (they come from the Infinity Cache instead).
-  // Either way a workgroup keeps its cout block for all iterations (resident-weight variants rely on it).
-  const int tiles_per_img = p.tiles_y * p.tiles_x;
-  const int grid = grid_override > 0 ? grid_override : std::min(256, p.ntiles), n_pt = p.ntiles / ncb;   // (override: a share of a merged launch)
-  const bool xcd_group = ncb > 1 && grid == 256 && 32 % ncb == 0 && (int64_t)p.Cout * p.Cin * 9 * ESZ <= (1 << 23);
-  std::vector<int4> tile((size_t)p.iters * grid);
-  for (int it = 0; it < p.iters; ++it)
-    for (int w = 0; w < grid; ++w) {
-      int cb, pt;
-      if (xcd_group) {
-        const int xcd = w % 8, slot = w / 8;
-        cb = slot % ncb;
-        pt = it * (grid / ncb) + (slot / ncb) * 8 + xcd;
-      } else {
-        const int T_ = it * grid + w;
-        cb = T_ % ncb; pt = T_ / ncb;
-      }
-      const int valid = pt < n_pt ? 1 : 0, t = pt % tiles_per_img;
-      const int img0 = valid ? (pt / tiles_per_img) * p.IMGS : 0, oy0 = (t / p.tiles_x) * p.TH, ox0 = (t % p.tiles_x) * p.TW;
-      const int mrow = mask_row_of(img0, oy0, ox0);
-      DH_REQUIRE(mrow < 4096, "conv3x3: too many distinct tile positions for the mask table");
-      const int64_t win_off = (int64_t)img0 * p.Hi * p.Wi * p.Cin * ESZ + (int64_t)((oy0 * STRIDE) * p.Wi + ox0 * STRIDE) * p.in_px_bytes;
-      const int64_t out_off = (int64_t)img0 * p.o_img + (int64_t)oy0 * p.o_row + (int64_t)ox0 * p.o_px + p.o_base + (int64_t)cb * p.out_cb;
-      DH_REQUIRE(win_off < ((int64_t)1 << 32) && out_off < ((int64_t)1 << 32), "conv3x3: tensor larger than 4 Gi elements / bytes");
-      tile[(size_t)it * grid + w] = make_int4(cb | (valid << 16) | (mrow << 20), (int)(uint32_t)win_off, (int)(uint32_t)out_off, 0);
-    }
+  dh_conv3::HostTables ht;   // pure integer host code (conv3_tables_host.h; swept under sanitizers by tests/test_conv_tables_host.py)
+  if (const char* why = dh_conv3::build_tables<STRIDE, NT, WAVES, ESZ, MT>(p, ncb, grid_override, &ht)) { dh::set_error("%s", why); return DH_EINVAL; }
+  static_assert(sizeof(dh_conv3::TileDesc) == sizeof(int4), "tile descriptor = int4");
+  const std::vector<int>& lane = ht.lane;
+  const std::vector<dh_conv3::TileDesc>& tile = ht.tile;
+  const std::vector<unsigned>& mask = ht.mask;
   Conv3Tables tb;
   DH_HIP(hipMalloc((void**)&tb.lane, lane.size() * sizeof(int)));
   DH_HIP(hipMalloc((void**)&tb.tile, tile.size() * sizeof(int4)));
@@ -938,36 +844,13 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     p.HPH = 0;
     // 512-pixel tiles (NT = 2) when that still gives every CU a tile; small batches of small maps (training at
     // batch 64: 14x14 and 7x7) drop to 256- and 128-pixel tiles instead of leaving half the chip idle
-    auto ntiles_of = [&](int th, int tw, int imgs) {
-      return ((B + imgs - 1) / imgs) * ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw) * (L.cout / 64);
-    };
     int variant;  // 0: NT=2 MT=2 (512 px)   1: NT=1 MT=2 (256 px)   2: NT=1 MT=1 (128 px)
     // candidates from the largest tile down; the first that gives every CU a tile wins, else the smallest (round 3: a launch
     // with few pixels -- a parity class of a stride-2 data gradient at batch 64 -- used to run 512-pixel tiles on half the chip)
-    struct Cand { int th, tw, imgs, hp, variant; };
-    Cand cands[4];
-    int nc = 0;
-    if (Wo > 16) {
-      // 16x32 or 8x64 output pixels, whichever wastes fewer tile slots (56x56: 77 % vs 88 % useful)
-      const int slots_a = ((Ho + 15) / 16) * ((Wo + 31) / 32), slots_b = ((Ho + 7) / 8) * ((Wo + 63) / 64);
-      if (slots_b < slots_a) cands[nc++] = {8, 64, 1, 66, 0};
-      else cands[nc++] = {16, 32, 1, 34, 0};
-      cands[nc++] = {16, 16, 1, 18, 1};
-    } else if (Wo > 8) {
-      cands[nc++] = {16, 16, 2, 18, 0};
-      cands[nc++] = {16, 16, 1, 18, 1};
-      cands[nc++] = {8, 8, 2, 12, 2};
-    } else {
-      cands[nc++] = {8, 8, 4, 12, 1};   // pitch 12: see lane_pos
-      cands[nc++] = {8, 8, 2, 12, 2};
-    }
-    int pick = nc - 1;
     static const int min_tiles = getenv("DH_CONV_MIN_TILES") ? atoi(getenv("DH_CONV_MIN_TILES")) : 256;
-    for (int i = 0; i < nc; ++i)
-      if (ntiles_of(cands[i].th, cands[i].tw, cands[i].imgs) >= min_tiles) { pick = i; break; }
-    p.TH = cands[pick].th; p.TW = cands[pick].tw; p.IMGS = cands[pick].imgs; p.HP = cands[pick].hp; variant = cands[pick].variant;
-    p.HR = p.TH + 2; p.HC = p.TW + 2;
-    p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
+    const dh_conv3::Cand cd = dh_conv3::pick_stride1(B, Ho, Wo, L.cout, min_tiles);   // conv3_tables_host.h
+    dh_conv3::set_stride1_geometry(p, cd, Ho, Wo);
+    variant = cd.variant;
     if ((rc = maybe_sample(variant == 0 && CLS < 0))) return rc;
     // weights resident in LDS when the layer has one cout block and its slabs fit beside the window ring (bf16 64 -> 64)
     const size_t wres_lds = (size_t)L.cin * sizeof(T) / CHUNK_BYTES * 9 * SLAB_TAP + 2 * (((size_t)p.IMGS * p.HR * p.HP * CHUNK_BYTES + 1023) & ~(size_t)1023) + 1024;
@@ -982,10 +865,7 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
        : variant == 1 ? launch_conv3x3_cfg<T, 1, 1, 8>(p, L, st)
                       : launch_conv3x3_cfg<T, 1, 1, 8, false, 1>(p, L, st);
   } else {
-    if (Wo > 8) { p.TH = 8; p.TW = 16; p.IMGS = 1; }
-    else { p.TH = 8; p.TW = 8; p.IMGS = 2; }
-    p.HR = 2 * p.TH + 1; p.HC = 2 * p.TW + 1; p.HPH = p.TW + 1; p.HP = 2 * p.HPH;
-    p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
+    dh_conv3::set_stride2_geometry(p, Ho, Wo);   // conv3_tables_host.h
     // 128-pixel tiles, 8 waves: wave pairs share pixels and split the 64 couts (two waves per SIMD)
     const size_t wres_lds = (size_t)L.cin * sizeof(T) / CHUNK_BYTES * (ds ? 10 : 9) * SLAB_TAP
                           + 2 * (((size_t)p.IMGS * p.HR * p.HP * CHUNK_BYTES + 1023) & ~(size_t)1023) + 2048;

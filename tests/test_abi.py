@@ -11,8 +11,8 @@ import pytest
 REPO = Path(__file__).resolve().parents[1]
 
 
-def declared_symbols():
-    text = (REPO / "include" / "deephisto_hip.h").read_text()
+def declared_symbols(header="deephisto_hip.h"):
+    text = (REPO / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(dh_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,6 +26,29 @@ def test_header_symbols_exported_and_bound(built_lib):
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in deephisto_amd/_lib.py"
     assert sorted(_lib.SIGNATURES) == syms
     assert built_lib.dh_abi_version() == 1
+    assert not [s for s in syms if "debug" in s], "test hooks belong in include/deephisto_hip_debug.h, not in the boundary header"
+
+
+def test_debug_header_symbols_exported_and_bound(built_lib):
+    """The per-kernel test hooks live in their own, unversioned header: still exported, still bound."""
+    from deephisto_amd import _lib
+    syms = declared_symbols("deephisto_hip_debug.h")
+    assert len(syms) >= 20 and all("debug" in s for s in syms)
+    for s in syms:
+        assert hasattr(built_lib, s), f"{s} declared in include/deephisto_hip_debug.h but not exported"
+    assert sorted(_lib.DEBUG_SIGNATURES) == syms
+    assert not set(_lib.DEBUG_SIGNATURES) & set(_lib.SIGNATURES)
+
+
+def test_library_exports_exactly_the_two_headers(built_lib):
+    """`nm -D` of the shared object: every exported dh_* symbol is declared in one of the two headers, and vice versa."""
+    import shutil
+    import subprocess
+    from deephisto_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("dh_")})
+    assert exported == sorted(declared_symbols() + declared_symbols("deephisto_hip_debug.h"))
 
 
 def test_tile_grid_host_entry_matches_reference(built_lib, golden_meta, golden_grids):
