@@ -1443,5 +1443,7 @@ extern "C" int dh_debug_stamps(int32_t enable, unsigned long long* out64_host) {
 
 #include "train.inc"
 #include "train2_kernels.inc"
+#include "wgrad_ring.inc"
+#include "bn_fold.inc"
 #include "gemm1x1.inc"
 #include "train2.inc"

@@ -210,6 +210,35 @@ def test_fused_backward_adam_equals_backward_then_adam(dev, arch):
         assert la == lb and torch.equal(ga, gb)
 
 
+@pytest.mark.parametrize("arch,B,P", [("resnet18", 6, 96), ("resnet50", 4, 128)])
+def test_bn_fold_is_bit_identical(dev, arch, B, P, monkeypatch):
+    """Round 4: on small maps the BN apply passes add the partial rows of their own 64-channel slice in their
+    prologue (bn_fold.inc) instead of waiting for a finalize launch.  The prologue adds the rows in the finalize kernel's own order,
+    so an engine created with DH_T2_FOLD=0 (finalize launches everywhere) gives the same losses, logits, parameters and running
+    statistics, bit for bit, over three optimiser steps."""
+    from deephisto_amd.models.patch_cls_simple.model import get_model
+    g = torch.Generator().manual_seed(47)
+    x = torch.rand(B, 3, P, P, generator=g).to(dev)
+    y = torch.randint(0, 5, (B,), generator=g).to(dev)
+    runs = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("DH_T2_FOLD", fold)
+        torch.manual_seed(5)
+        m = get_model(5, "bf16", arch=arch).to(dev).train()
+        trace = []
+        for _ in range(3):
+            loss, logits = m.train_step(x, y, lr=1e-3)
+            trace.append((float(loss), logits.clone()))
+        eng = m._bf16_engine() if arch == "resnet18" else m._engine
+        runs.append((trace, eng.flat(0, dev).clone(), eng.flat(2, dev).clone()))
+        del m
+    (ta, pa, ra), (tb, pb, rb) = runs
+    for (la, ga), (lb, gb) in zip(ta, tb):
+        assert la == lb and torch.equal(ga, gb)
+    assert torch.equal(pa, pb) and torch.equal(ra, rb)
+    assert bool(torch.isfinite(pa).all())
+
+
 @pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
 def test_join_bn_fusion_is_bit_identical(dev, arch, monkeypatch):
     """The downsample branch's BN applied inside the join BN's pass (bn2_apply_join_kernel: the branch value rounded to bf16 where the

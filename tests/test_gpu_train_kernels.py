@@ -266,10 +266,12 @@ def test_gemm1x1_bf16_kernel(dev, M, N, K, stride):
     (3, 1, 64, 64, 3, 56), (3, 1, 256, 256, 4, 14), (3, 2, 128, 128, 3, 28), (3, 1, 512, 512, 5, 7), (3, 1, 128, 128, 2, 12),
     (1, 1, 64, 256, 3, 56), (1, 1, 256, 64, 2, 28),          # 64 x 64 tiles (64-channel layers)
     (1, 1, 512, 128, 3, 28), (1, 1, 256, 1024, 4, 14), (1, 1, 2048, 512, 5, 7), (1, 2, 256, 512, 3, 28), (1, 1, 1024, 256, 2, 6),   # 128 x 128 tiles
+    (1, 1, 1024, 256, 64, 14), (1, 2, 512, 1024, 8, 28), (1, 1, 64, 256, 64, 56), (1, 1, 128, 128, 1, 5),   # round 4: ring kernel at bench shapes / many slabs / one partial step
 ])
 def test_wgrad_bf16_kernels(dev, ks, stride, cin, cout, B, H):
-    """dW through the transposed-LDS-read kernels (3x3 tap groups, 1x1 with 64 x 64 and 128 x 128 workgroup tiles; odd maps, stride 2,
-    row pitches that are not multiples of 4) against torch autograd in float64 on the same bf16 operands: relative L2 <= 1e-5
+    """dW through the transposed-LDS-read kernels (3x3 tap groups, 1x1 with 64 x 64 tiles, and -- round 4 -- the LDS-DMA ring kernel
+    with four-quadrant tiles over flat 64-pixel steps, wgrad_ring.inc; odd maps, stride 2, a pixel count that is not a multiple of
+    64, row pitches that are not multiples of 4) against torch autograd in float64 on the same bf16 operands: relative L2 <= 1e-5
     (exact products, f32 accumulation)."""
     from deephisto_amd._lib import check, lib
     g = torch.Generator().manual_seed(ks * 1000 + cin + cout + H)

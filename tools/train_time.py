@@ -8,8 +8,13 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from deephisto_amd.models.patch_cls_simple.model import get_model
 B, P = 64, 224
-args = [a for a in sys.argv[1:] if not a.startswith("--")] or ["resnet50", "resnet18bf16", "resnet18"]
-steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 60
+argv = sys.argv[1:]
+steps = 60
+if "--steps" in argv:
+    i = argv.index("--steps")
+    steps = int(argv[i + 1])
+    del argv[i:i + 2]
+args = [a for a in argv if not a.startswith("--")] or ["resnet50", "resnet18bf16", "resnet18"]
 dev = torch.device("cuda:0")
 for arch in args:
     torch.manual_seed(0)
