@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 import ctypes as C
+import os
 
 from .. import tiles
 from .._lib import DH_LAYOUT_NCHW, check, lib
@@ -193,8 +194,17 @@ def predict_full_patched(sampler: FullImageDenseSampler, model: ResNet18HIP, n_c
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     lo, hi = shard_range(n_unique, world, rank)
-    if hi - lo > mb:   # equal launches instead of full ones plus a short tail (4 802 tiles per rank at 8 GPUs: 5 x 961)
-        mb = -(-(hi - lo) // -(-(hi - lo) // mb))
+    if hi - lo > mb:
+        # near-equal launches instead of full ones plus a short tail, each a MULTIPLE OF 128 TILES (all but the last): the persistent
+        # kernels run one tile per workgroup per iteration on 256 CUs (stem: 768 workgroups), and a layer has 8 / 4 / 2 / 2 conv tiles
+        # per 256 x 256 image, so only multiples of 128 images fill the last iteration of every layer.  38 416 tiles as 10 x 3 842 paid
+        # an almost empty extra iteration in every layer of every launch (121 instead of 120.06 in layer 1, 31 instead of 30.02 in
+        # layers 3-4, 26 instead of 25.01 in the stem: ~2 % of the slide); 9 x 3 968 + 2 704 does not.
+        k = -(-(hi - lo) // mb)
+        per = -(-(hi - lo) // k)
+        mb = min(mb, max(128, -(-per // 128) * 128)) if mb >= 128 else per
+        if os.environ.get("DH_MB_ALIGN") == "0":   # A/B: the round-3 rule (equal launches, any size)
+            mb = per
     o_dev = torch.from_numpy(origins[lo:hi]).to(dev)
     per_rank = -(-n_unique // world)
     local = torch.zeros((per_rank, n_classes), dtype=torch.float32, device=dev)
