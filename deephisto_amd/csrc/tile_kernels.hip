@@ -140,6 +140,23 @@ struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
 
 constexpr int GATHER_ROWS = 16;  // tile rows per 256-thread block (4 per wave)
 
+// The gathered tiles are written once and read by a later kernel (0.8 GB per 1 024 tiles: far past the 256 MB Infinity Cache), the slide
+// bytes are read once: non-temporal accesses keep neither in the caches.  Measured (tools/hbm_mix_peak.hip: the same 1 : 4 byte mix as a
+// linear stream reaches 5.1-5.4 TB/s plain, 5.4-5.5 TB/s non-temporal; profiles/r04_exp_tiler.txt for the kernels).
+#ifndef DH_TILER_NT
+#define DH_TILER_NT 1
+#endif
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_f4(float* p, float a, float b, float c, float d) {
+  if (DH_TILER_NT) __builtin_nontemporal_store(f4v_t{a, b, c, d}, reinterpret_cast<f4v_t*>(p));
+  else *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void st_u2(uint16_t* p, uint32_t x, uint32_t y) {
+  if (DH_TILER_NT) __builtin_nontemporal_store(u2v_t{x, y}, reinterpret_cast<u2v_t*>(p));
+  else *reinterpret_cast<uint2*>(p) = make_uint2(x, y);
+}
+
 // NCHW: one wave = one tile row; lane j owns pixels 4j..4j+3 (12 contiguous bytes) and
 // writes one 16-B (f32) / 8-B (bf16) store into each of the three planes.
 template <bool BF16>
@@ -167,13 +184,10 @@ __global__ __launch_bounds__(256) void gather_nchw_kernel(const uint8_t* __restr
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           if constexpr (BF16) {
-            uint2 w;
-            w.x = f32_to_bf16_bits(f[c][0]) | (f32_to_bf16_bits(f[c][1]) << 16);
-            w.y = f32_to_bf16_bits(f[c][2]) | (f32_to_bf16_bits(f[c][3]) << 16);
-            *reinterpret_cast<uint2*>(static_cast<uint16_t*>(outv) + o + c * plane) = w;
+            st_u2(static_cast<uint16_t*>(outv) + o + c * plane, f32_to_bf16_bits(f[c][0]) | (f32_to_bf16_bits(f[c][1]) << 16),
+                  f32_to_bf16_bits(f[c][2]) | (f32_to_bf16_bits(f[c][3]) << 16));
           } else {
-            *reinterpret_cast<float4*>(static_cast<float*>(outv) + o + c * plane) =
-                make_float4(f[c][0], f[c][1], f[c][2], f[c][3]);
+            st_f4(static_cast<float*>(outv) + o + c * plane, f[c][0], f[c][1], f[c][2], f[c][3]);
           }
         }
       }
@@ -204,12 +218,9 @@ __global__ __launch_bounds__(256) void gather_nhwc_kernel(const uint8_t* __restr
                     f2 = div255((v >> 16) & 0xFFu), f3 = div255(v >> 24);
         const int64_t o = ((int64_t)t * P + r) * rowlen + bj;
         if constexpr (BF16) {
-          uint2 w;
-          w.x = f32_to_bf16_bits(f0) | (f32_to_bf16_bits(f1) << 16);
-          w.y = f32_to_bf16_bits(f2) | (f32_to_bf16_bits(f3) << 16);
-          *reinterpret_cast<uint2*>(static_cast<uint16_t*>(outv) + o) = w;
+          st_u2(static_cast<uint16_t*>(outv) + o, f32_to_bf16_bits(f0) | (f32_to_bf16_bits(f1) << 16), f32_to_bf16_bits(f2) | (f32_to_bf16_bits(f3) << 16));
         } else {
-          *reinterpret_cast<float4*>(static_cast<float*>(outv) + o) = make_float4(f0, f1, f2, f3);
+          st_f4(static_cast<float*>(outv) + o, f0, f1, f2, f3);
         }
       }
     }
