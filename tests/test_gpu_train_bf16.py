@@ -13,7 +13,8 @@ a randomly initialised network with batch-statistic BN -- measured values in bra
   logits vs bf16-emulating oracle   <= 3e-2                              [6e-3 .. 9e-3]
   loss   vs float32 oracle          <= 1e-2                              [1e-4]
   conv outputs vs float32 oracle    <= 1e-1 relative L2 per conv         [<= 5e-2]
-  gradients vs bf16-emulating oracle with the engine's ReLU patterns: relative L2 <= 8e-2 per tensor  [<= 4.2e-2]
+  gradients vs bf16-emulating oracle with the engine's ReLU patterns, stored activations, loss gradient and gradient rounding
+  points imposed: relative L2 <= 2e-2 per tensor  [<= 1.5e-2; the stem's BN bias <= 5e-2, measured <= 3.6e-2: see GRAD_GATE_LOOSE]
 The ResNet-50 cases damp every block's last BN gain to 0.2 (any parameter values are legitimate for an arithmetic check):
 with gain ~1 a random-init 50-layer network amplifies bf16 rounding to tens of percent at the logits in BOTH the engine and
 the bf16-emulating oracle (measured: 0.6 relative L2 at the last conv), which says nothing about the kernels."""
@@ -30,6 +31,15 @@ from oracle import resnet50 as o50
 from oracle.bf16_emulation import forward_bf16
 
 pytestmark = pytest.mark.gpu
+
+# Composition gate of the backward pass (round 4, VERDICT r3 item 5: was 8e-2): relative L2 per gradient tensor against the bf16-emulating
+# oracle run with the ENGINE's ReLU patterns, the engine's stored activations as the operands of every layer (`forced`), the engine's loss
+# gradient, and bf16 rounding of every activation gradient where the engine stores one (`grad_rounding`).  What is left is summation order and
+# the exact position of a few roundings; it accumulates from the loss down: measured <= 1.5e-2 at layer 1 / the stem, <= 1e-2 above.
+GRAD_GATE = 2e-2
+# the stem's BN bias: its gradient is the plain sum of ALL masked gradient elements at the bottom of the network (0.4-3 M signed terms that
+# cancel to a fraction of their norm), so the bf16 rounding of each term shows undamped: measured 1.2e-2 ... 3.6e-2 over the six cases
+GRAD_GATE_LOOSE = {"bn1.bias": 5e-2}
 
 
 @pytest.fixture(scope="module")
@@ -98,14 +108,22 @@ def test_forward_backward_vs_oracles(dev, arch, B, P, gain):
     # gradients: bf16-emulating oracle with the engine's ReLU patterns imposed
     masks = {name: _act(m, name, 1, a.shape, dev) > 0 for name, a in acts.items() if "downsample" not in name}
     emu.zero_grad()
-    F.cross_entropy(forward_bf16(emu, x, None, masks), y).backward()
+    # ... and the ENGINE's loss gradient: dL/dlogits = (softmax(engine logits) - onehot) / B.  The two forwards differ by up to 3e-2 in
+    # the logits, which alone moves every gradient by percents; with it imposed what is compared is the backward pass
+    dl = (torch.softmax(got, 1) - F.one_hot(y, 5).float()) / B
+    forced = {name: _act(m, name, 1, a.shape, dev) for name, a in acts.items() if "downsample" not in name}   # ... and its stored activations
+    (forward_bf16(emu, x, None, masks, grad_rounding=True, forced=forced) * dl).sum().backward()
     want = {k: p.grad for k, p in emu.named_parameters()}
-    bad = {}
+    bad, worst = {}, ("", 0.0)
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         e = float((p.grad.cpu() - want[k]).norm() / (want[k].norm() + 1e-30))
-        if e > 8e-2:
+        if e > worst[1]:
+            worst = (k, e)
+        if e > GRAD_GATE_LOOSE.get(k, GRAD_GATE):
             bad[k] = e
+    errs = sorted(((float((p.grad.cpu() - want[k]).norm() / (want[k].norm() + 1e-30)), k) for k, p in m.named_parameters()), reverse=True)
+    print(f"[grad gate] {arch} B={B} P={P}: worst tensors " + ", ".join(f"{k} {e:.4f}" for e, k in errs[:5]))
     assert not bad, bad
     # running statistics and the batch counter went through
     sd, sr = m.state_dict(), ref.state_dict()
@@ -374,8 +392,8 @@ def test_shape_sweep_forward_backward(dev, arch, B, P):
     for k in ("fc.weight", "fc.bias"):
         e = float((dict(m.named_parameters())[k].grad.cpu() - want[k].grad).norm() / (want[k].grad.norm() + 1e-30))
         assert e <= 0.15, (k, e)
-    # every gradient tensor against the emulation with the ENGINE's ReLU patterns imposed (the gate of test_forward_backward_vs_oracles,
-    # here at the sweep's shapes: 7 x 7 and 5 x 5 maps, 64-pixel-wide wgrad rows)
+    # every gradient tensor against the emulation with the ENGINE's ReLU patterns, activations and loss gradient imposed (the 2e-2 gate of
+    # test_forward_backward_vs_oracles, here at the sweep's shapes: 7 x 7 and 5 x 5 maps, 64-pixel-wide wgrad rows)
     shapes = {}
     hooks = [mod.register_forward_hook(lambda _m, _i, o, name=name: shapes.__setitem__(name, tuple(o.shape)))
              for name, mod in ref.named_modules() if isinstance(mod, torch.nn.Conv2d)]
@@ -386,11 +404,17 @@ def test_shape_sweep_forward_backward(dev, arch, B, P):
     masks = {name: _act(m, name, 1, shp, dev) > 0 for name, shp in shapes.items() if "downsample" not in name}
     emu2 = copy.deepcopy(ref)
     emu2.zero_grad()
-    F.cross_entropy(forward_bf16(emu2, x, None, masks), y).backward()
+    dl = (torch.softmax(out.detach().cpu(), 1) - F.one_hot(y, 5).float()) / B     # the engine's own loss gradient (see test_forward_backward_vs_oracles)
+    forced = {name: _act(m, name, 1, shp, dev) for name, shp in shapes.items() if "downsample" not in name}
+    (forward_bf16(emu2, x, None, masks, grad_rounding=True, forced=forced) * dl).sum().backward()
     want2 = {k: p.grad for k, p in emu2.named_parameters()}
-    bad = {}
+    bad, worst = {}, ("", 0.0)
     for k, p in m.named_parameters():
         e = float((p.grad.cpu() - want2[k]).norm() / (want2[k].norm() + 1e-30))
-        if e > 8e-2:
+        if e > worst[1]:
+            worst = (k, e)
+        if e > GRAD_GATE_LOOSE.get(k, GRAD_GATE):
             bad[k] = e
+    errs = sorted(((float((p.grad.cpu() - want2[k]).norm() / (want2[k].norm() + 1e-30)), k) for k, p in m.named_parameters()), reverse=True)
+    print(f"[grad gate] sweep {arch} B={B} P={P}: worst tensors " + ", ".join(f"{k} {e:.4f}" for e, k in errs[:5]))
     assert not bad, bad
