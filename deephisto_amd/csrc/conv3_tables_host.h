@@ -5,7 +5,7 @@
 // asserting that every offset lies inside its tensor and fits its integer type (tests/test_conv_tables_host.py, CPU only).
 //
 // `P` is any struct with the geometry fields of Conv3Params (TH, TW, IMGS, HR, HC, HP, HPH, Hi, Wi, Cin, B, tiles_y, tiles_x,
-// n_win_instr, in_px_bytes, Ho, Wo, Cout, out_px, out_cb, o_img, o_row, o_px, o_base, ntiles, iters).
+// n_win_instr, in_px_bytes, Ho, Wo, Cout, out_px, out_cb, o_img, o_row, o_px, o_base, r_row, r_px, r_cb, r_base, ntiles, iters).
 #pragma once
 #include <algorithm>
 #include <array>
@@ -17,10 +17,10 @@ namespace dh_conv3 {
 
 constexpr int kChunkBytes = 64;   // channel bytes of one pixel staged per pass (CHUNK_BYTES)
 
-struct TileDesc { int x, y, z, w; };   // {cout block | valid << 16 | mask row << 20, window byte offset, output element offset, 0}
+struct TileDesc { int x, y, z, w; };   // {cout block | valid << 16 | mask row << 20, window byte offset, output element offset, residual element offset}
 
 struct HostTables {
-  std::vector<int> lane;        // [threads][2 NT + MAXJ] = {out_rel[NT], base_lin[NT], rel_off[MAXJ]}
+  std::vector<int> lane;        // [threads][3 NT + MAXJ] = {out_rel[NT], base_lin[NT], res_rel[NT], rel_off[MAXJ]}
   std::vector<TileDesc> tile;   // [iters][grid]
   std::vector<unsigned> mask;   // [mask rows][threads]: bits 0..MAXJ-1 window piece j inside the image, bit 16 + nt: pixel nt exists
   int grid = 0, threads = 0, lane_stride = 0, mask_rows = 0;
@@ -74,11 +74,24 @@ template <class P> inline void set_stride1_geometry(P& p, const Cand& c, int Ho,
   p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
 }
 
+// the wide stride-2 variant (conv3x3.inc, HALF): 256-pixel tiles, 8 x 32 output pixels or 16 x 16
+template <class P> inline bool set_stride2_wide_geometry(P& p, int Ho, int Wo) {
+  if (Wo > 16) { p.TH = 8; p.TW = 32; }
+  else if (Wo > 8) { p.TH = 16; p.TW = 16; }
+  else return false;
+  p.IMGS = 1;
+  p.HR = 2 * p.TH + 1; p.HC = 2 * p.TW + 1; p.HPH = p.TW + 1; p.HP = 2 * p.HPH;
+  p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
+  return true;
+}
+
 // Returns nullptr, or the reason the shape cannot be scheduled.  `grid_override` > 0: the launch's share of a merged launch.
-template <int STRIDE, int NT, int WAVES, int ESZ, int MT, class P>
+// HALF: half-chunk stages of the wide stride-2 variant -- a window piece (1 KiB) is 32 pixels x 32 bytes (lane l: pixel l >> 1, landing
+// slot l & 1, which holds global slot (l & 1) ^ ((pixel >> 3) & 1)); waves pair up on pixels although each owns two cout tiles.
+template <int STRIDE, int NT, int WAVES, int ESZ, int MT, class P, bool HALF = false>
 const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out) {
   constexpr int MAXJ = max_window_pieces<STRIDE, NT, WAVES>();
-  const int threads = WAVES * 64, stride = 2 * NT + MAXJ;
+  const int threads = WAVES * 64, stride = 3 * NT + MAXJ;
   std::vector<int>& lane = out->lane;
   lane.assign((size_t)threads * stride, 0);
   // per-thread geometry kept for the mask rows below: output pixel (ty, tx, img) per n-tile, window piece (hy, hx, img, live)
@@ -101,7 +114,7 @@ const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out
       return (in_a ? 0 : 8) + (rank < 8 ? rank : rank + 8);   // TW == 8: A -> rows 0, 2; B -> rows 1, 3
     };
     for (int nt = 0; nt < NT; ++nt) {
-      const int pidx = ((MT == 2 ? wave : wave >> 1) * NT + nt) * 32 + lane_pos(l & 31);   // MT == 1: wave pairs share pixels
+      const int pidx = ((MT == 2 && !HALF ? wave : wave >> 1) * NT + nt) * 32 + lane_pos(l & 31);   // MT == 1 / HALF: wave pairs share pixels
       const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
       const int ty = rem / p.TW, tx = rem % p.TW;
       pix[(size_t)tid * NT + nt] = {ty, tx, img};
@@ -109,21 +122,24 @@ const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out
       if (orel < 0 || orel > INT32_MAX) return "conv3x3: per-lane output offset does not fit 31 bits";
       row[nt] = (int)orel;
       row[NT + nt] = (img * p.HR + ty * STRIDE) * p.HP + tx;
+      const int64_t rrel = (int64_t)img * p.o_img + (int64_t)ty * p.r_row + (int64_t)tx * p.r_px;   // the residual's own layout
+      if (rrel < 0 || rrel > INT32_MAX) return "conv3x3: per-lane residual offset does not fit 31 bits";
+      row[2 * NT + nt] = (int)rrel;
     }
     // window DMA: instruction i = wave + WAVES*j fills LDS pixels 16i..16i+15; lane l fills LDS slot (l&3)
     // of pixel 16i + l/4 with GLOBAL slot (l&3) ^ swizzle(pixel)
     for (int j = 0; j < MAXJ; ++j) {
       const int i = wave + WAVES * j;
-      const int px = i * 16 + (l >> 2);
+      const int px = HALF ? i * 32 + (l >> 1) : i * 16 + (l >> 2);
       const int img = px / (p.HR * p.HP), r = px % (p.HR * p.HP);
       const int hy = r / p.HP, c = r % p.HP;
       int hx = c;
       if (STRIDE == 2) hx = 2 * (c % p.HPH) + c / p.HPH;
       const bool live = i < p.n_win_instr && img < p.IMGS && hx < p.HC;
-      const int g = (l & 3) ^ ((px >> 2) & 3);
+      const int g = HALF ? (l & 1) ^ ((px >> 3) & 1) : (l & 3) ^ ((px >> 2) & 3);
       const int64_t roff = (int64_t)img * img_in_bytes + ((int64_t)(hy - 1) * p.Wi + hx - 1) * p.in_px_bytes + g * 16;
       if (live && (roff < INT32_MIN || roff > INT32_MAX)) return "conv3x3: per-lane window offset does not fit 32 bits";
-      row[2 * NT + j] = live ? (int)roff : 0;   // (dead pieces are never dereferenced: their mask bit is clear in every row)
+      row[3 * NT + j] = live ? (int)roff : 0;   // (dead pieces are never dereferenced: their mask bit is clear in every row)
       win[(size_t)tid * MAXJ + j] = {hy, hx, img, live ? 1 : 0};
     }
   }
@@ -183,8 +199,9 @@ const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out
       if (mrow >= 4096) return "conv3x3: too many distinct tile positions for the mask table";
       const int64_t win_off = (int64_t)img0 * img_in_bytes + ((int64_t)(oy0 * STRIDE) * p.Wi + ox0 * STRIDE) * p.in_px_bytes;
       const int64_t out_off = (int64_t)img0 * p.o_img + (int64_t)oy0 * p.o_row + (int64_t)ox0 * p.o_px + p.o_base + (int64_t)cb * p.out_cb;
-      if (win_off >= ((int64_t)1 << 32) || out_off >= ((int64_t)1 << 32)) return "conv3x3: tensor larger than 4 Gi elements / bytes";
-      tile[(size_t)it * grid + w] = TileDesc{cb | (valid << 16) | (mrow << 20), (int)(uint32_t)win_off, (int)(uint32_t)out_off, 0};
+      const int64_t res_off = (int64_t)img0 * p.o_img + (int64_t)oy0 * p.r_row + (int64_t)ox0 * p.r_px + p.r_base + (int64_t)cb * p.r_cb;
+      if (win_off >= ((int64_t)1 << 32) || out_off >= ((int64_t)1 << 32) || res_off >= ((int64_t)1 << 32)) return "conv3x3: tensor larger than 4 Gi elements / bytes";
+      tile[(size_t)it * grid + w] = TileDesc{cb | (valid << 16) | (mrow << 20), (int)(uint32_t)win_off, (int)(uint32_t)out_off, (int)(uint32_t)res_off};
     }
   out->grid = grid; out->threads = threads; out->lane_stride = stride; out->mask_rows = (int)mask_row.size(); out->xcd_group = xcd_group;
   return nullptr;

@@ -518,6 +518,7 @@ struct ConvLayer {
   std::string bn;
   int cin, cout, ks, stride;
   void* w_dev = nullptr;        // packed weights
+  void* w2_dev = nullptr;       // bf16 inference, stride-2 3x3 convs with cout % 128 == 0 and their downsample convs: the wide (HALF) packing
   float* scale_dev = nullptr;   // [cout]
   float* shift_dev = nullptr;
 };
@@ -601,6 +602,24 @@ void pack_conv_weights(const float* w, int cout, int cin, int ks, int esz, std::
                 if (esz == 4) { memcpy(&out[o], &v, 4); o += 4; }
                 else { const uint16_t hb = host_bf16(v); memcpy(&out[o], &hb, 2); o += 2; }
               }
+}
+
+// The wide stride-2 variant's packing (conv3x3.inc, HALF): [cb = cout/128][hc = cin/16][tap][mt (4)][lane][8 bf16]; element e of lane l:
+//   co = 128 cb + 32 mt + (l & 31); ci = 16 hc + 8 (l >> 5) + e.   (ks = 1: one "tap" per (cb, hc): 4 KiB)
+void pack_conv_weights_wide(const float* w, int cout, int cin, int ks, std::vector<uint8_t>& out) {
+  const int taps = ks * ks, ncb = cout / 128, nhc = cin / 16;
+  out.assign((size_t)ncb * nhc * taps * SLAB_TAP, 0);
+  size_t o = 0;
+  for (int cb = 0; cb < ncb; ++cb)
+    for (int hc = 0; hc < nhc; ++hc)
+      for (int tap = 0; tap < taps; ++tap)
+        for (int mt = 0; mt < 4; ++mt)
+          for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 8; ++e) {
+              const int co = cb * 128 + mt * 32 + (l & 31), ci = hc * 16 + (l >> 5) * 8 + e;
+              const uint16_t hb = host_bf16(w[((size_t)co * cin + ci) * taps + tap]);
+              memcpy(&out[o], &hb, 2); o += 2;
+            }
 }
 
 // Stem weights [64][3][7][7].  bf16: [kh][t][mt][lane][8], slot i = 16t + 8h + j,
@@ -722,11 +741,12 @@ struct Conv3Tables { int* lane = nullptr; int4* tile = nullptr; unsigned* mask =
 std::map<std::vector<int>, Conv3Tables> g_conv3_tables;
 constexpr size_t CONV3_TABLE_CAP = 256;
 
-template <int STRIDE, int NT, int WAVES, int ESZ, int MT>
+template <int STRIDE, int NT, int WAVES, int ESZ, int MT, bool HALF = false>
 int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out, int grid_override = 0) {
-  const std::vector<int> key = {current_device(), STRIDE, NT, WAVES, MT, ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi,
+  const std::vector<int> key = {current_device(), STRIDE, NT, WAVES, MT + (HALF ? 100 : 0), ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi,
                                 p.Cin, p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes, p.Ho, p.Wo, p.Cout, p.out_px,
-                                p.out_cb, (int)(p.o_img & 0x7FFFFFFF), (int)(p.o_img >> 31), p.o_row, p.o_px, p.o_base, grid_override, p.iters};
+                                p.out_cb, (int)(p.o_img & 0x7FFFFFFF), (int)(p.o_img >> 31), p.o_row, p.o_px, p.o_base, grid_override, p.iters,
+                                p.r_row, p.r_px, p.r_cb, p.r_base};
   std::lock_guard<std::mutex> lk(g_host_mu);
   auto it = g_conv3_tables.find(key);
   if (it != g_conv3_tables.end()) { *out = it->second; return DH_OK; }
@@ -735,7 +755,7 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
     g_conv3_tables.clear();
   }
   dh_conv3::HostTables ht;   // pure integer host code (conv3_tables_host.h; swept under sanitizers by tests/test_conv_tables_host.py)
-  if (const char* why = dh_conv3::build_tables<STRIDE, NT, WAVES, ESZ, MT>(p, ncb, grid_override, &ht)) { dh::set_error("%s", why); return DH_EINVAL; }
+  if (const char* why = dh_conv3::build_tables<STRIDE, NT, WAVES, ESZ, MT, Conv3Params, HALF>(p, ncb, grid_override, &ht)) { dh::set_error("%s", why); return DH_EINVAL; }
   static_assert(sizeof(dh_conv3::TileDesc) == sizeof(int4), "tile descriptor = int4");
   const std::vector<int>& lane = ht.lane;
   const std::vector<dh_conv3::TileDesc>& tile = ht.tile;
@@ -753,27 +773,28 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
   return DH_OK;
 }
 
-template <typename T, int STRIDE, int NT, int WAVES, bool DS = false, int MT = 2, bool WRES = false, int CLS = -1>
+template <typename T, int STRIDE, int NT, int WAVES, bool DS = false, int MT = 2, bool WRES = false, int CLS = -1, bool HALF = false>
 int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
-  const int win_bytes = p.IMGS * p.HR * p.HP * CHUNK_BYTES;
+  constexpr int STAGE_PX_BYTES = HALF ? CHUNK_BYTES / 2 : CHUNK_BYTES, CO_BLK = HALF ? 128 : 64;
+  const int win_bytes = p.IMGS * p.HR * p.HP * STAGE_PX_BYTES;
   const size_t wslab = (size_t)(9 + (DS ? 1 : 0)) * SLAB_TAP, win_alloc = (win_bytes + 1023) & ~1023;
-  const size_t nchunks = (size_t)L.cin * sizeof(T) / CHUNK_BYTES;
+  const size_t nchunks = (size_t)L.cin * sizeof(T) / STAGE_PX_BYTES;
   // 2-deep ring of [weight slab | window] (WRES: all weight slabs once + ring of windows) + [2][scale|shift(|ds scale|ds shift)]
-  const size_t lds = (WRES ? nchunks * wslab + 2 * win_alloc : 2 * (wslab + win_alloc)) + (DS ? 2048 : 1024);
+  const size_t lds = (WRES ? nchunks * wslab + 2 * win_alloc : 2 * (wslab + win_alloc)) + (HALF ? 4096 : DS ? 2048 : 1024);
 
   constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
-  p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
+  p.n_win_instr = HALF ? (p.IMGS * p.HR * p.HP + 31) / 32 : (p.IMGS * p.HR * p.HP + 15) / 16;
   DH_REQUIRE(p.n_win_instr <= MAXJ * WAVES, "conv3x3: staging window too large for the DMA plan");
   DH_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS budget exceeded (%zu B)", lds);
-  DH_REQUIRE(p.IMGS * p.TH * p.TW == (WAVES * MT / 2) * NT * 32, "conv3x3: tile/pixel mismatch");
+  DH_REQUIRE(p.IMGS * p.TH * p.TW == (HALF ? WAVES / 2 : WAVES * MT / 2) * NT * 32, "conv3x3: tile/pixel mismatch");
   DH_REQUIRE(L.cin * (int)sizeof(T) >= 2 * CHUNK_BYTES, "conv3x3: needs at least two channel chunks");
   const int groups = ((p.B + p.IMGS - 1) / p.IMGS) * p.tiles_y * p.tiles_x;
-  p.ntiles = groups * (L.cout / 64);
+  p.ntiles = groups * (L.cout / CO_BLK);
   const int grid = std::min(256, p.ntiles);  // persistent: one workgroup per CU
   DH_REQUIRE(!WRES || grid % (L.cout / 64) == 0, "conv3x3: resident weights need a fixed cout block per workgroup");
   p.iters = (p.ntiles + grid - 1) / grid;
   Conv3Tables tb;
-  int rc = conv3_tables<STRIDE, NT, WAVES, (int)sizeof(T), MT>(p, L.cout / 64, groups, &tb);
+  int rc = conv3_tables<STRIDE, NT, WAVES, (int)sizeof(T), MT, HALF>(p, L.cout / CO_BLK, groups, &tb);
   if (rc) return rc;
   p.lane_tab = tb.lane; p.tile_tab = tb.tile; p.mask_tab = tb.mask;
   if constexpr (CLS >= 0) {   // parity class of a stride-2 data gradient: no cycle-stamped twin
@@ -782,12 +803,19 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
     DH_LAUNCH_CHECK();
     return DH_OK;
   }
-  if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES>), 160 * 1024)) ||
-      (rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>), 160 * 1024))) return rc;
-  if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
-  else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES, -1, HALF>), 160 * 1024)) ||
+      (rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES, -1, HALF>), 160 * 1024))) return rc;
+  if (p.stamps) hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, true, DS, MT, WRES, -1, HALF>), dim3(grid), dim3(WAVES * 64), lds, st, p);
+  else hipLaunchKernelGGL((conv3x3_kernel<T, STRIDE, NT, WAVES, false, DS, MT, WRES, -1, HALF>), dim3(grid), dim3(WAVES * 64), lds, st, p);
   DH_LAUNCH_CHECK();
   return DH_OK;
+}
+
+// Will a 3x3 / stride-2 conv + fused downsample of this shape run on the wide kernel (conv3x3.inc, HALF)?  Then its INPUT must be written in
+// 16-channel planes by the conv before it (forward_impl decides with this before launching that conv).
+inline bool s2_wide_eligible(const ConvLayer& c1, const ConvLayer& ds, int esz, int Wo) {
+  static const bool on = !(getenv("DH_CONV_S2_WIDE") && atoi(getenv("DH_CONV_S2_WIDE")) == 0);
+  return on && esz == 2 && c1.w2_dev && ds.w2_dev && c1.cout % 128 == 0 && Wo > 8;
 }
 
 // CLS >= 0: parity class (CLS >> 1, CLS & 1) of a stride-2 data gradient -- `in` = dZ [B][Hi][Wi][L.cin], Ho x Wo = the class's
@@ -795,9 +823,10 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
 template <typename T, int STRIDE, int CLS = -1>
 int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* out, int B, int Hi, int Wi,
                    bool relu, hipStream_t st, int Ho, int Wo, const ConvLayer* ds = nullptr, void* ds_out = nullptr,
-                   bool blocked = false, int full_h = 0, int full_w = 0) {
+                   bool blocked = false, int full_h = 0, int full_w = 0, bool in16 = false, bool out16 = false) {
   Conv3Params p;
   static_assert(CLS < 0 || STRIDE == 1, "parity classes run on the stride-1 kernel");
+  DH_REQUIRE(blocked || (!in16 && !out16), "conv3x3: 16-channel planes are a variant of the channel-blocked layout");
   DH_REQUIRE(CLS < 0 || (!blocked && !ds && full_h > 0 && full_w > 0), "conv3x3: a parity class needs the NHWC layout and the size of dX");
   DH_REQUIRE(!blocked || sizeof(T) == 2, "conv3x3: the channel-blocked layout is the bf16 inference layout");
   if (blocked) {   // [image][C/32][H][W][32]
@@ -813,6 +842,15 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
   } else {
     p.o_img = (int64_t)Ho * Wo * L.cout; p.o_row = Wo * p.out_px; p.o_px = p.out_px; p.o_base = 0;
   }
+  // the residual shares the output's layout ...
+  p.out_pr = 16; p.res_mt = p.out_mt; p.res_pr = 16; p.r_row = p.o_row; p.r_px = p.o_px; p.r_cb = p.out_cb; p.r_base = p.o_base;
+  // ... unless this conv writes 16-channel planes [image][C/16][H][W][16] for the wide stride-2 kernel that follows (conv3x3.inc, HALF:
+  // its half-chunk stages then read whole cache lines); the residual -- the block's input -- stays in 32-channel planes
+  if (out16) {
+    p.out_px = 16; p.out_pr = Ho * Wo * 16; p.out_mt = 2 * p.out_pr; p.out_cb = 2 * p.out_mt;
+    p.o_row = Wo * 16; p.o_px = 16;
+  }
+  if (in16) { p.in_px_bytes = 32; p.in_chunk_bytes = Hi * Wi * 32; }
   p.ds_w = ds ? ds->w_dev : nullptr; p.ds_scale = ds ? ds->scale_dev : nullptr;
   p.ds_shift = ds ? ds->shift_dev : nullptr; p.ds_out = ds_out;
   p.in = in; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = out;
@@ -865,6 +903,18 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
        : variant == 1 ? launch_conv3x3_cfg<T, 1, 1, 8>(p, L, st)
                       : launch_conv3x3_cfg<T, 1, 1, 8, false, 1>(p, L, st);
   } else {
+    // round 4: the wide variant (128 couts x 256 pixels per workgroup on half-chunk stages; conv3x3.inc, HALF) where its packing exists
+    // (bf16 inference, fused downsample, cout % 128 == 0) and the map is at least 16 pixels wide.  DH_CONV_S2_WIDE=0: the 128-pixel kernel
+    static const bool s2_wide = !(getenv("DH_CONV_S2_WIDE") && atoi(getenv("DH_CONV_S2_WIDE")) == 0);
+    if constexpr (sizeof(T) == 2) {
+      if (in16) {
+        DH_REQUIRE(s2_wide && ds && blocked && L.w2_dev && ds->w2_dev && L.cout % 128 == 0 && dh_conv3::set_stride2_wide_geometry(p, Ho, Wo),
+                   "conv3x3: an input in 16-channel planes needs the wide stride-2 kernel");
+        p.w = L.w2_dev; p.ds_w = ds->w2_dev;
+        p.out_cb = 4 * p.out_mt;   // a workgroup's cout block = four 32-cout planes
+        return launch_conv3x3_cfg<T, 2, 2, 8, true, 2, false, -1, true>(p, L, st);
+      }
+    }
     dh_conv3::set_stride2_geometry(p, Ho, Wo);   // conv3_tables_host.h
     // 128-pixel tiles, 8 waves: wave pairs share pixels and split the 64 couts (two waves per SIMD)
     const size_t wres_lds = (size_t)L.cin * sizeof(T) / CHUNK_BYTES * (ds ? 10 : 9) * SLAB_TAP
@@ -962,6 +1012,7 @@ int launch_dgrad_s2(const ConvLayer& L, const void* dz, const void* res, void* d
     p.in_px_bytes = L.cin * (int)sizeof(T); p.in_chunk_bytes = CHUNK_BYTES;
     p.out_px = L.cout; p.out_mt = 32; p.out_cb = 64;
     p.o_img = (int64_t)Hi * Wi * L.cout; p.o_row = 2 * Wi * L.cout; p.o_px = 2 * L.cout; p.o_base = 0;
+    p.out_pr = 16; p.res_mt = p.out_mt; p.res_pr = 16; p.r_row = p.o_row; p.r_px = p.o_px; p.r_cb = p.out_cb; p.r_base = 0;
     for (int c = 0; c < 4; ++c) p.cls_base[c] = ((c >> 1) * Wi + (c & 1)) * L.cout;
     p.ds_w = nullptr; p.ds_scale = nullptr; p.ds_shift = nullptr; p.ds_out = nullptr;
     p.in = dz; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = dx;
@@ -1018,6 +1069,7 @@ int launch_dgrad_s2(const ConvLayer& L, const void* dz, const void* res, void* d
     p.out_px = L.cout; p.out_mt = 32; p.out_cb = 64;
     p.o_img = (int64_t)Hi * Wi * L.cout; p.o_row = 2 * Wi * L.cout; p.o_px = 2 * L.cout;
     p.o_base = ((id >> 1) * Wi + (id & 1)) * L.cout;
+    p.out_pr = 16; p.res_mt = p.out_mt; p.res_pr = 16; p.r_row = p.o_row; p.r_px = p.o_px; p.r_cb = p.out_cb; p.r_base = p.o_base;
     p.ds_w = nullptr; p.ds_scale = nullptr; p.ds_shift = nullptr; p.ds_out = nullptr;
     p.in = dz; p.w = L.w_dev; p.scale = L.scale_dev; p.shift = L.shift_dev; p.res = res; p.out = dx;
     p.B = B; p.Hi = Ho; p.Wi = Wo; p.Cin = L.cin; p.Cout = L.cout; p.Ho = rows; p.Wo = cols;
@@ -1034,13 +1086,14 @@ int launch_dgrad_s2(const ConvLayer& L, const void* dz, const void* res, void* d
 
 template <typename T>
 int run_conv(const ConvLayer& L, const void* in, const void* res, void* out, int B, int Hi, int Wi,
-             bool relu, hipStream_t st, int* Ho_out, int* Wo_out, bool blocked = false) {
+             bool relu, hipStream_t st, int* Ho_out, int* Wo_out, bool blocked = false, bool out16 = false) {
   const int pad = L.ks / 2;
   const int Ho = (Hi + 2 * pad - L.ks) / L.stride + 1, Wo = (Wi + 2 * pad - L.ks) / L.stride + 1;
   *Ho_out = Ho; *Wo_out = Wo;
   DH_REQUIRE((int64_t)B * Hi * Wi * L.cin * (int64_t)sizeof(T) < ((int64_t)1 << 32),
              "conv %s: input larger than 4 GiB, reduce the batch", L.name.c_str());
-  if (L.ks == 3 && L.stride == 1) return launch_conv3x3<T, 1>(L, in, res, out, B, Hi, Wi, relu, st, Ho, Wo, nullptr, nullptr, blocked);
+  if (L.ks == 3 && L.stride == 1) return launch_conv3x3<T, 1>(L, in, res, out, B, Hi, Wi, relu, st, Ho, Wo, nullptr, nullptr, blocked, 0, 0, false, out16);
+  DH_REQUIRE(!out16, "conv %s: only the stride-1 3x3 kernel writes 16-channel planes", L.name.c_str());
   if (L.ks == 3 && L.stride == 2) return launch_conv3x3<T, 2>(L, in, res, out, B, Hi, Wi, relu, st, Ho, Wo, nullptr, nullptr, blocked);
   DH_REQUIRE(!blocked, "conv %s: only the 3x3 kernels read the channel-blocked layout", L.name.c_str());
   ConvParams p;
@@ -1152,31 +1205,48 @@ int forward_impl(dh_resnet18* net, const float* x, const uint8_t* slide, int64_t
   constexpr bool BLK = sizeof(T) == 2;
   int H = H2, W = H2;
   size_t ci = 1;
+  bool x16 = false;   // X holds the block input in 16-channel planes (written that way for the wide stride-2 kernel)
+  void* X = bufA;     // block input / output; bufB: the block's intermediate; `other`: the third buffer
   for (int s = 0; s < 4; ++s) {
     for (int blk = 0; blk < 2; ++blk) {
       const bool has_ds = (blk == 0 && s > 0);
       const ConvLayer& c1 = net->convs[ci];
       const ConvLayer& c2 = net->convs[ci + 1];
+      void* other = X == bufA ? bufC : bufA;
       int Ho, Wo, h2, w2;
       int rc;
-      const void* resid = bufA;
+      const void* resid = X;
       if (has_ds) {
         // conv1 (3x3/2 + BN + ReLU) and the 1x1/2 downsample (+ BN) of the block in ONE launch
         Ho = (H + 2 - 3) / 2 + 1; Wo = (W + 2 - 3) / 2 + 1;
-        rc = launch_conv3x3<T, 2>(c1, bufA, nullptr, bufB, B, H, W, true, st, Ho, Wo, &net->convs[ci + 2], bufC, BLK);
+        rc = launch_conv3x3<T, 2>(c1, X, nullptr, bufB, B, H, W, true, st, Ho, Wo, &net->convs[ci + 2], other, BLK, 0, 0, x16, false);
         if (rc) return rc;
-        resid = bufC;
+        resid = other;
       } else {
-        rc = run_conv<T>(c1, bufA, nullptr, bufB, B, H, W, true, st, &Ho, &Wo, BLK);
+        DH_REQUIRE(!x16, "resnet18 forward: only a downsample block reads 16-channel planes");
+        rc = run_conv<T>(c1, X, nullptr, bufB, B, H, W, true, st, &Ho, &Wo, BLK);
         if (rc) return rc;
       }
-      rc = run_conv<T>(c2, bufB, resid, bufA, B, Ho, Wo, true, st, &h2, &w2, BLK);
+      // the block that follows starts with a stride-2 conv on the wide kernel: this block's output goes out in 16-channel planes
+      x16 = false;
+      if (blk == 1 && s < 3) {
+        const ConvLayer& n1 = net->convs[ci + 2];
+        const ConvLayer& nds = net->convs[ci + 4];
+        x16 = BLK && s2_wide_eligible(n1, nds, esz, (Wo + 2 - 3) / 2 + 1);
+      }
+      // conv2 + residual.  Same layout: in place over the residual (every lane reads the elements it then writes).  16-channel planes out,
+      // 32-channel planes in: the two layouts put different pixels at the same address -- the output goes to the third buffer
+      void* O = X;
+      if (has_ds) O = X;                 // the block input is dead once conv1 and the downsample have run (stream order)
+      else if (x16) O = other;
+      rc = run_conv<T>(c2, bufB, resid, O, B, Ho, Wo, true, st, &h2, &w2, BLK, x16);
       if (rc) return rc;
+      X = O;
       H = Ho; W = Wo;
       ci += has_ds ? 3 : 2;
     }
   }
-  hipLaunchKernelGGL((avgpool_fc_kernel<T>), dim3(B), dim3(256), 0, st, static_cast<const T*>(bufA), H * W,
+  hipLaunchKernelGGL((avgpool_fc_kernel<T>), dim3(B), dim3(256), 0, st, static_cast<const T*>(X), H * W,
                      512, BLK ? 1 : 0, net->fc_w_dev, net->fc_b_dev, net->n_classes, logits);
   DH_LAUNCH_CHECK();
   return DH_OK;
@@ -1210,6 +1280,7 @@ extern "C" void dh_resnet18_destroy(dh_resnet18* net) {
   if (net->train) (void)dh_resnet18_train_end(net);
   for (auto& c : net->convs) {
     if (c.w_dev) (void)hipFree(c.w_dev);
+    if (c.w2_dev) (void)hipFree(c.w2_dev);
     if (c.scale_dev) (void)hipFree(c.scale_dev);
     if (c.shift_dev) (void)hipFree(c.shift_dev);
   }
@@ -1252,6 +1323,14 @@ extern "C" int dh_resnet18_finalize(dh_resnet18* net, void* stream) {
     else pack_conv_weights(w->data(), c.cout, c.cin, c.ks, esz, packed);
     int rc = upload(packed, &c.w_dev);
     if (rc) return rc;
+    // the wide stride-2 variant's packing: a 3x3 / stride-2 conv of a downsample block and that block's 1x1 / stride-2 conv (bf16 inference)
+    const bool wide3 = esz == 2 && c.ks == 3 && c.stride == 2 && c.cout % 128 == 0 && c.cin % 16 == 0;
+    const bool wide1 = esz == 2 && c.ks == 1 && c.stride == 2 && c.cout % 128 == 0 && c.cin % 16 == 0;
+    if (wide3 || wide1) {
+      std::vector<uint8_t> packed2;
+      pack_conv_weights_wide(w->data(), c.cout, c.cin, c.ks, packed2);
+      if ((rc = upload(packed2, &c.w2_dev))) return rc;
+    }
     // eval-mode BN (eps = 1e-5, torch default): y = x*scale + shift
     std::vector<float> sc(c.cout), sh(c.cout);
     for (int k = 0; k < c.cout; ++k) {

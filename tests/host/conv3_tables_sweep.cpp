@@ -24,25 +24,29 @@ struct Geom {   // the geometry fields of Conv3Params
   int B, Hi, Wi, Cin, Ho, Wo, Cout;
   int in_px_bytes, in_chunk_bytes, out_px, out_cb, out_mt;
   int64_t o_img; int o_row, o_px, o_base;
+  int out_pr, res_mt, res_pr, r_row, r_px, r_cb, r_base;   // output half-tile stride; the residual's own layout
   int TH, TW, IMGS, tiles_y, tiles_x, HR, HC, HP, HPH, n_win_instr, ntiles, iters;
 };
 
 static long g_cases = 0;
 #define REQUIRE(cond, ...) do { if (!(cond)) { fprintf(stderr, "VIOLATION %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); abort(); } } while (0)
 
-template <int STRIDE, int NT, int WAVES, int ESZ, int MT>
-static void check_case(Geom p, bool blocked, int grid_override, const char* what) {
+// layout of the output / input: 0 NHWC, 1 channel-blocked in 32-channel planes, 2 in 16-channel planes (out16 / in16)
+template <int STRIDE, int NT, int WAVES, int ESZ, int MT, bool HALF = false>
+static void check_case(Geom p, int in_layout, int out_layout, int grid_override, const char* what) {
   constexpr int MAXJ = max_window_pieces<STRIDE, NT, WAVES>();
-  const int ncb = p.Cout / 64;
-  p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
+  constexpr int CO_BLK = HALF ? 128 : 64, PXB = HALF ? 32 : 64;   // couts per workgroup; bytes of a pixel per stage
+  const bool blocked = in_layout != 0;
+  const int ncb = p.Cout / CO_BLK;
+  p.n_win_instr = HALF ? (p.IMGS * p.HR * p.HP + 31) / 32 : (p.IMGS * p.HR * p.HP + 15) / 16;
   REQUIRE(p.n_win_instr <= MAXJ * WAVES, "%s: window too large for the DMA plan", what);
-  REQUIRE(p.IMGS * p.TH * p.TW == (WAVES * MT / 2) * NT * 32, "%s: tile/pixel mismatch", what);
+  REQUIRE(p.IMGS * p.TH * p.TW == (HALF ? WAVES / 2 : WAVES * MT / 2) * NT * 32, "%s: tile/pixel mismatch", what);
   const int groups = ((p.B + p.IMGS - 1) / p.IMGS) * p.tiles_y * p.tiles_x;
   p.ntiles = groups * ncb;
   const int grid = grid_override > 0 ? grid_override : std::min(256, p.ntiles);
   p.iters = (p.ntiles + grid - 1) / grid;
   HostTables ht;
-  const char* why = build_tables<STRIDE, NT, WAVES, ESZ, MT>(p, ncb, grid_override, &ht);
+  const char* why = build_tables<STRIDE, NT, WAVES, ESZ, MT, Geom, HALF>(p, ncb, grid_override, &ht);
   const int64_t in_bytes = (int64_t)p.B * p.Hi * p.Wi * p.Cin * ESZ;
   const int64_t out_elems = (int64_t)p.B * p.o_img;
   if (why) {   // the only legitimate refusal: a tensor past 4 Gi bytes / elements
@@ -52,7 +56,7 @@ static void check_case(Geom p, bool blocked, int grid_override, const char* what
   }
   REQUIRE(ht.grid == grid && ht.mask_rows < 4096 && (int)ht.tile.size() == p.iters * grid, "%s: table sizes", what);
   const int threads = WAVES * 64;
-  const int nchunks = p.Cin * ESZ / kChunkBytes;
+  const int nchunks = p.Cin * ESZ / PXB;
   // written[(pixel, cout block)] exactly once
   std::vector<uint8_t> written((size_t)p.B * p.Ho * p.Wo * ncb, 0);
   std::vector<int> wg_cb(grid, -1);
@@ -85,16 +89,20 @@ static void check_case(Geom p, bool blocked, int grid_override, const char* what
         for (int j = 0; j < MAXJ; ++j) {
           const int i = wave + WAVES * j;
           if (i >= p.n_win_instr) { REQUIRE(!((mk >> j) & 1u), "%s: mask bit on an unissued piece", what); continue; }
-          const int px = i * 16 + (l >> 2);
+          const int px = HALF ? i * 32 + (l >> 1) : i * 16 + (l >> 2);
           if (!((mk >> j) & 1u)) continue;
           for (int ch = 0; ch < nchunks; ch += std::max(1, nchunks - 1)) {   // first and last chunk
-            const int64_t src = (int64_t)win_off + (int64_t)ch * p.in_chunk_bytes + row[2 * NT + j];
+            const int64_t src = (int64_t)win_off + (int64_t)ch * p.in_chunk_bytes + row[3 * NT + j];
             REQUIRE(src >= 0 && src + 16 <= in_bytes, "%s: window piece reads [%" PRId64 ", +16) outside the %" PRId64 "-byte input (tile it %d wg %d tid %d j %d)",
                     what, src, in_bytes, it, w, tid, j);
             // which pixel / slot is it?  NHWC: byte = ((img * Hi + y) * Wi + x) * Cin * ESZ + chunk * 64 + slot * 16
             //                            blocked: byte = (img * nchunks + chunk) * Hi * Wi * 64 + (y * Wi + x) * 64 + slot * 16
             int64_t simg, sy, sx, sch, sslot;
-            if (blocked) {
+            if (in_layout == 2) {          // 16-channel planes: [image][C/16][H][W][16] -- a plane IS a half-chunk
+              simg = src / img_bytes; const int64_t r = src % img_bytes;
+              sch = r / ((int64_t)p.Hi * p.Wi * 32); const int64_t r2 = r % ((int64_t)p.Hi * p.Wi * 32);
+              sy = r2 / (p.Wi * 32); sx = (r2 % (p.Wi * 32)) / 32; sslot = (r2 % 32) / 16;
+            } else if (blocked) {
               simg = src / img_bytes; const int64_t r = src % img_bytes;
               sch = r / ((int64_t)p.Hi * p.Wi * 64); const int64_t r2 = r % ((int64_t)p.Hi * p.Wi * 64);
               sy = r2 / (p.Wi * 64); sx = (r2 % (p.Wi * 64)) / 64; sslot = (r2 % 64) / 16;
@@ -107,8 +115,8 @@ static void check_case(Geom p, bool blocked, int grid_override, const char* what
             const int hy = lr / p.HP, c = lr % p.HP;
             const int hx = STRIDE == 2 ? 2 * (c % p.HPH) + c / p.HPH : c;
             REQUIRE(simg == img0 + limg && sy == iy0 + hy - 1 && sx == ix0 + hx - 1 && sch == ch, "%s: window piece lands on the wrong pixel", what);
-            REQUIRE(sslot == ((l & 3) ^ ((px >> 2) & 3)), "%s: swizzle slot", what);
-            if (ch == 0) staged[(size_t)px * 4 + (l & 3)] = 1;
+            if (HALF) { REQUIRE(sslot == ((l & 1) ^ ((px >> 3) & 1)), "%s: swizzle slot (half)", what); if (ch == 0) { staged[(size_t)px * 4 + (l & 1)] = 1; staged[(size_t)px * 4 + 2 + (l & 1)] = 1; } }
+            else { REQUIRE(sslot == ((l & 3) ^ ((px >> 2) & 3)), "%s: swizzle slot", what); if (ch == 0) staged[(size_t)px * 4 + (l & 3)] = 1; }
           }
         }
         // ---- output pixels (epilogue_of): out + out_off + out_rel[nt] + mt * out_mt + 32 couts
@@ -117,16 +125,36 @@ static void check_case(Geom p, bool blocked, int grid_override, const char* what
           const int64_t base = (int64_t)out_off + row[nt];
           REQUIRE(base <= UINT32_MAX, "%s: output offset past 32 bits", what);
           for (int ml = 0; ml < MT; ++ml) {
-            const int mt = MT == 2 ? ml : (wave & 1);
-            const int64_t e0 = base + (int64_t)mt * p.out_mt;
-            REQUIRE(e0 >= 0 && e0 + 32 <= out_elems, "%s: output [%" PRId64 ", +32) outside %" PRId64 " elements", what, e0, out_elems);
+            const int mt = HALF ? 2 * (wave & 1) + ml : MT == 2 ? ml : (wave & 1);
+            for (int pr = 0; pr < 2; ++pr) {   // the two 16-cout halves of a 32-cout tile (epilogue_of: + pr * out_pr + h * 8)
+              const int64_t e0 = base + (int64_t)mt * p.out_mt + (int64_t)pr * p.out_pr;
+              REQUIRE(e0 >= 0 && e0 + 16 <= out_elems, "%s: output [%" PRId64 ", +16) outside %" PRId64 " elements", what, e0, out_elems);
+            }
           }
-          if ((l >> 5) == 0 && (MT == 2 || (wave & 1) == 0)) {   // one owner per pixel: half-wave 0 (the other half holds the other couts)
+          {   // the residual tile (prefetch_residual: res + td.w + res_rel + mt * res_mt + pr * res_pr + h * 8), always in its own layout
+            const int64_t rbase = (int64_t)(uint32_t)td.w + row[2 * NT + nt];
+            for (int ml = 0; ml < MT; ++ml) {
+              const int mt = HALF ? 2 * (wave & 1) + ml : MT == 2 ? ml : (wave & 1);
+              const int64_t e0 = rbase + (int64_t)mt * p.res_mt + p.res_pr;
+              REQUIRE(e0 >= 0 && e0 + 16 <= out_elems, "%s: residual [%" PRId64 ", +16) outside %" PRId64 " elements", what, e0, out_elems);
+            }
+            // ... and it is the SAME pixel / cout block as the output (NHWC / 32-channel planes)
+            int64_t rpix;
+            if (blocked) { const int64_t r = rbase % p.o_img; rpix = (rbase / p.o_img) * p.Ho * p.Wo + (r % ((int64_t)p.Ho * p.Wo * 32)) / 32; REQUIRE(r / ((int64_t)p.Ho * p.Wo * 32) == (CO_BLK / 32) * cb, "%s: residual cout block", what); }
+            else { rpix = rbase / p.Cout; REQUIRE(rbase % p.Cout == cb * CO_BLK, "%s: residual cout block (NHWC)", what); }
+            int64_t opix;
+            if (out_layout == 2) { const int64_t r = base % p.o_img; opix = (base / p.o_img) * p.Ho * p.Wo + (r % ((int64_t)p.Ho * p.Wo * 16)) / 16; }
+            else if (out_layout == 1) { const int64_t r = base % p.o_img; opix = (base / p.o_img) * p.Ho * p.Wo + (r % ((int64_t)p.Ho * p.Wo * 32)) / 32; }
+            else opix = base / p.Cout;
+            REQUIRE(rpix == opix, "%s: residual pixel %" PRId64 " != output pixel %" PRId64, what, rpix, opix);
+          }
+          if ((l >> 5) == 0 && ((MT == 2 && !HALF) || (wave & 1) == 0)) {   // one owner per pixel: half-wave 0 (the other half holds the other couts)
             // pixel index from the element offset (dense maps only: o_px == out_px)
             if (p.o_px == p.out_px && p.o_base == 0) {
               int64_t pix;
-              if (blocked) { const int64_t r = base % p.o_img; pix = (base / p.o_img) * p.Ho * p.Wo + (r % ((int64_t)p.Ho * p.Wo * 32)) / 32; REQUIRE(r / ((int64_t)p.Ho * p.Wo * 32) == 2 * cb, "%s: blocked cout block", what); }
-              else { pix = base / p.Cout; REQUIRE(base % p.Cout == cb * 64, "%s: NHWC cout block", what); }
+              if (out_layout == 2) { const int64_t r = base % p.o_img; pix = (base / p.o_img) * p.Ho * p.Wo + (r % ((int64_t)p.Ho * p.Wo * 16)) / 16; REQUIRE(r / ((int64_t)p.Ho * p.Wo * 16) == (CO_BLK / 16) * cb, "%s: 16-plane cout block", what); }
+              else if (out_layout == 1) { const int64_t r = base % p.o_img; pix = (base / p.o_img) * p.Ho * p.Wo + (r % ((int64_t)p.Ho * p.Wo * 32)) / 32; REQUIRE(r / ((int64_t)p.Ho * p.Wo * 32) == (CO_BLK / 32) * cb, "%s: blocked cout block", what); }
+              else { pix = base / p.Cout; REQUIRE(base % p.Cout == cb * CO_BLK, "%s: NHWC cout block", what); }
               REQUIRE(pix >= 0 && pix < (int64_t)p.B * p.Ho * p.Wo, "%s: pixel index", what);
               uint8_t& f = written[(size_t)pix * ncb + cb];
               REQUIRE(f == 0, "%s: output pixel %" PRId64 " cout block %d written twice", what, pix, cb);
@@ -152,19 +180,32 @@ static void check_case(Geom p, bool blocked, int grid_override, const char* what
   ++g_cases;
 }
 
+// out16: the output in 16-channel planes (the conv before a wide stride-2 conv); wide: the wide stride-2 variant itself (input in 16-channel planes)
 template <int ESZ>
-static void sweep_layer(int B, int Hi, int cin, int cout, int stride, bool blocked, int min_tiles, const std::string& tag) {
+static void sweep_layer(int B, int Hi, int cin, int cout, int stride, bool blocked, int min_tiles, const std::string& tag, bool out16 = false, bool wide = false) {
   Geom p{};
   p.B = B; p.Hi = Hi; p.Wi = Hi; p.Cin = cin; p.Cout = cout;
   p.Ho = (Hi + 2 - 3) / stride + 1; p.Wo = p.Ho;
   if (blocked) { p.in_px_bytes = kChunkBytes; p.in_chunk_bytes = Hi * Hi * kChunkBytes; p.out_px = 32; p.out_mt = p.Ho * p.Wo * 32; p.out_cb = 2 * p.out_mt; }
   else { p.in_px_bytes = cin * ESZ; p.in_chunk_bytes = kChunkBytes; p.out_px = cout; p.out_mt = 32; p.out_cb = 64; }
   p.o_img = (int64_t)p.Ho * p.Wo * cout; p.o_row = p.Wo * p.out_px; p.o_px = p.out_px; p.o_base = 0;
+  p.out_pr = 16; p.res_mt = p.out_mt; p.res_pr = 16; p.r_row = p.o_row; p.r_px = p.o_px; p.r_cb = p.out_cb; p.r_base = 0;
+  if (out16) { p.out_px = 16; p.out_pr = p.Ho * p.Wo * 16; p.out_mt = 2 * p.out_pr; p.out_cb = 2 * p.out_mt; p.o_row = p.Wo * 16; p.o_px = 16; }
+  if (wide) { p.in_px_bytes = 32; p.in_chunk_bytes = Hi * Hi * 32; }
   const std::string what = tag + " B=" + std::to_string(B) + " Hi=" + std::to_string(Hi) + " " + std::to_string(cin) + "->" + std::to_string(cout) +
-                           " s" + std::to_string(stride) + (blocked ? " blocked" : " nhwc") + " esz" + std::to_string(ESZ);
+                           " s" + std::to_string(stride) + (blocked ? " blocked" : " nhwc") + (out16 ? " out16" : "") + (wide ? " wide" : "") + " esz" + std::to_string(ESZ);
+  const int in_l = wide ? 2 : blocked ? 1 : 0, out_l = out16 ? 2 : blocked ? 1 : 0;
   if (stride == 2) {
+    if (wide) {
+      if constexpr (ESZ == 2) {
+        REQUIRE(set_stride2_wide_geometry(p, p.Ho, p.Wo), "%s: no wide geometry", what.c_str());
+        p.out_cb = 4 * p.out_mt; p.r_cb = p.out_cb;
+        check_case<2, 2, 8, ESZ, 2, true>(p, in_l, out_l, 0, what.c_str());
+      }
+      return;
+    }
     set_stride2_geometry(p, p.Ho, p.Wo);
-    check_case<2, 1, 8, ESZ, 1>(p, blocked, 0, what.c_str());
+    check_case<2, 1, 8, ESZ, 1>(p, in_l, out_l, 0, what.c_str());
     return;
   }
   Cand c[4];
@@ -173,9 +214,9 @@ static void sweep_layer(int B, int Hi, int cin, int cout, int stride, bool block
   for (int i = 0; i < nc; ++i) {   // ALL candidates, not only the picked one
     set_stride1_geometry(p, c[i], p.Ho, p.Wo);
     const std::string w2 = what + " cand" + std::to_string(i) + (c[i].th == picked.th && c[i].tw == picked.tw && c[i].imgs == picked.imgs ? "*" : "");
-    if (c[i].variant == 0) check_case<1, 2, 8, ESZ, 2>(p, blocked, 0, w2.c_str());
-    else if (c[i].variant == 1) check_case<1, 1, 8, ESZ, 2>(p, blocked, 0, w2.c_str());
-    else check_case<1, 1, 8, ESZ, 1>(p, blocked, 0, w2.c_str());
+    if (c[i].variant == 0) check_case<1, 2, 8, ESZ, 2>(p, in_l, out_l, 0, w2.c_str());
+    else if (c[i].variant == 1) check_case<1, 1, 8, ESZ, 2>(p, in_l, out_l, 0, w2.c_str());
+    else check_case<1, 1, 8, ESZ, 1>(p, in_l, out_l, 0, w2.c_str());
   }
 }
 
@@ -194,6 +235,8 @@ int main(int argc, char** argv) {
       for (int s = 0; s < ly.shift; ++s) Hi = (Hi + 2 - 3) / 2 + 1;
       for (int n : ns_small) {
         sweep_layer<2>(n, Hi, ly.cin, ly.cout, ly.stride, true, 256, "inf-bf16");    // bf16 inference: channel-blocked
+        if (ly.stride == 1 && ly.cin == ly.cout) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 1, true, 256, "inf-bf16", true);   // ... writing 16-channel planes
+        if (ly.stride == 2 && ly.cout % 128 == 0 && (Hi + 2 - 3) / 2 + 1 > 8) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 2, true, 256, "inf-bf16", false, true);   // the wide stride-2 variant
         sweep_layer<2>(n, Hi, ly.cin, ly.cout, ly.stride, false, 256, "train-bf16"); // bf16 training: NHWC
         sweep_layer<4>(n, Hi, ly.cin, ly.cout, ly.stride, false, 256, "f32");
       }
@@ -203,6 +246,8 @@ int main(int argc, char** argv) {
         for (int n : ns_big) {
           if (!full && P == 256 && ly.shift > 1 && n != 4096) continue;
           sweep_layer<2>(n, Hi, ly.cin, ly.cout, ly.stride, true, 256, "inf-bf16");
+          if (ly.stride == 1 && ly.cin == ly.cout && ly.shift < 2) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 1, true, 256, "inf-bf16", true);
+          if (ly.stride == 2 && ly.cout % 128 == 0 && (Hi + 2 - 3) / 2 + 1 > 8) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 2, true, 256, "inf-bf16", false, true);
           if (n <= 1024) sweep_layer<4>(n, Hi, ly.cin, ly.cout, ly.stride, false, 256, "f32");
         }
     }
