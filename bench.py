@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--stride", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64, help="sampler batch size (grid padding unit)")
     ap.add_argument("--micro-batch", type=int, default=4096,
-                    help="tiles per kernel launch (the library's maximum; 38 416 tiles run as 10 equal launches of 3 842: measured "
+                    help="upper bound of the tiles per kernel launch (the library's maximum; 38 416 tiles run as 9 launches of 3 968 + one of 2 704 -- multiples of 128: measured "
                          "190.8 k patches/s at 1024, 194.7 k at 2048, 196.6 k at 4096 on one box -- prologue and tail of the persistent "
                          "kernels amortised over more tiles)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams (micro-batches in flight)")
@@ -445,7 +445,7 @@ def main():
         achieved = (k_flops_v / (k_ms_v * 1e-3)) / 1e12 if k_ms_v > 0 else 0.0
         flop_tile = FLOP_PER_TILE_256 * (args.patch / 256.0) ** 2
         traffic = None   # HBM bytes per launch of the dominant kernel: from the committed PMC passes (rocprofv3
-        pmc = next((q for q in (REPO / "profiles" / "r03_pmc_dominant_kernel.json", REPO / "profiles" / "r02_pmc_dominant_kernel.json",
+        pmc = next((q for q in (REPO / "profiles" / "r04_pmc_dominant_kernel.json", REPO / "profiles" / "r03_pmc_dominant_kernel.json", REPO / "profiles" / "r02_pmc_dominant_kernel.json",
                                 REPO / "profiles" / "r01_pmc_dominant_kernel.json") if q.exists()), REPO / "none")   # cannot run inside the timed process)
         if pmc.exists() and args.dtype == "bf16" and args.patch == 256:
             doc = json.loads(pmc.read_text())
