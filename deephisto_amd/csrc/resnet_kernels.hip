@@ -815,7 +815,7 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
 // 16-channel planes by the conv before it (forward_impl decides with this before launching that conv).
 inline bool s2_wide_eligible(const ConvLayer& c1, const ConvLayer& ds, int esz, int Wo) {
   static const bool on = !(getenv("DH_CONV_S2_WIDE") && atoi(getenv("DH_CONV_S2_WIDE")) == 0);
-  return on && esz == 2 && c1.w2_dev && ds.w2_dev && c1.cout % 128 == 0 && Wo > 8;
+  return on && esz == 2 && c1.w2_dev && ds.w2_dev && c1.cout % 128 == 0 && Wo > 4;
 }
 
 // CLS >= 0: parity class (CLS >> 1, CLS & 1) of a stride-2 data gradient -- `in` = dZ [B][Hi][Wi][L.cin], Ho x Wo = the class's

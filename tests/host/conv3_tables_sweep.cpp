@@ -236,7 +236,7 @@ int main(int argc, char** argv) {
       for (int n : ns_small) {
         sweep_layer<2>(n, Hi, ly.cin, ly.cout, ly.stride, true, 256, "inf-bf16");    // bf16 inference: channel-blocked
         if (ly.stride == 1 && ly.cin == ly.cout) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 1, true, 256, "inf-bf16", true);   // ... writing 16-channel planes
-        if (ly.stride == 2 && ly.cout % 128 == 0 && (Hi + 2 - 3) / 2 + 1 > 8) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 2, true, 256, "inf-bf16", false, true);   // the wide stride-2 variant
+        if (ly.stride == 2 && ly.cout % 128 == 0 && (Hi + 2 - 3) / 2 + 1 > 4) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 2, true, 256, "inf-bf16", false, true);   // the wide stride-2 variant
         sweep_layer<2>(n, Hi, ly.cin, ly.cout, ly.stride, false, 256, "train-bf16"); // bf16 training: NHWC
         sweep_layer<4>(n, Hi, ly.cin, ly.cout, ly.stride, false, 256, "f32");
       }
@@ -246,8 +246,8 @@ int main(int argc, char** argv) {
         for (int n : ns_big) {
           if (!full && P == 256 && ly.shift > 1 && n != 4096) continue;
           sweep_layer<2>(n, Hi, ly.cin, ly.cout, ly.stride, true, 256, "inf-bf16");
-          if (ly.stride == 1 && ly.cin == ly.cout && ly.shift < 2) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 1, true, 256, "inf-bf16", true);
-          if (ly.stride == 2 && ly.cout % 128 == 0 && (Hi + 2 - 3) / 2 + 1 > 8) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 2, true, 256, "inf-bf16", false, true);
+          if (ly.stride == 1 && ly.cin == ly.cout && ly.shift < 3) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 1, true, 256, "inf-bf16", true);
+          if (ly.stride == 2 && ly.cout % 128 == 0 && (Hi + 2 - 3) / 2 + 1 > 4) sweep_layer<2>(n, Hi, ly.cin, ly.cout, 2, true, 256, "inf-bf16", false, true);
           if (n <= 1024) sweep_layer<4>(n, Hi, ly.cin, ly.cout, ly.stride, false, 256, "f32");
         }
     }
