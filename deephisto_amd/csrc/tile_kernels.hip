@@ -574,3 +574,52 @@ extern "C" int dh_overlay_blend(const uint8_t* img, const uint8_t* col, int64_t 
   DH_LAUNCH_CHECK();
   return DH_OK;
 }
+
+// ---------------------------------------------------------------------------
+// e1: the one exchange step of the sharded whole-slide prediction (every rank contributes the logits of its
+// contiguous tile range, every rank receives all of them) as a C-ABI entry for hosts that are not torch.distributed programs.
+// `comm` is the caller's ncclComm_t (RCCL); RCCL is resolved at the first call from the process image -- the library the caller
+// created `comm` with -- so that this shared object carries no link-time dependency on it (the Python shims exchange through
+// torch.distributed, whose RCCL never gets here).  DH_RCCL_LIB names another file to load.
+// ---------------------------------------------------------------------------
+#include <dlfcn.h>
+namespace {
+typedef int (*rccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*rccl_errstr_fn)(int);
+struct RcclEntry { rccl_allgather_fn allgather = nullptr; rccl_errstr_fn errstr = nullptr; const char* why = nullptr; };
+const RcclEntry& rccl_entry() {
+  static const RcclEntry e = [] {
+    RcclEntry r;
+    void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");      // an RCCL with global symbols is already in the process
+    void* h = nullptr;
+    if (!sym) {
+      const char* names[3] = {getenv("DH_RCCL_LIB"), "librccl.so.1", "librccl.so"};   // by SONAME: glibc hands back a copy that is already loaded
+      for (const char* nm : names) {
+        if (!nm || !*nm) continue;
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+      }
+      if (h) sym = dlsym(h, "ncclAllGather");
+    }
+    if (!sym) { r.why = "RCCL not found (librccl.so.1; set DH_RCCL_LIB)"; return r; }
+    r.allgather = reinterpret_cast<rccl_allgather_fn>(sym);
+    r.errstr = reinterpret_cast<rccl_errstr_fn>(h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    return r;
+  }();
+  return e;
+}
+}  // namespace
+
+extern "C" int dh_allgather_logits(void* comm, const float* send_dev, float* recv_dev, int64_t n_per_rank, int32_t n_cls, void* stream) {
+  DH_REQUIRE(comm, "allgather_logits: null communicator");
+  DH_REQUIRE(n_per_rank >= 0 && n_cls > 0, "allgather_logits: bad sizes");
+  if (n_per_rank == 0) return DH_OK;
+  DH_REQUIRE(send_dev && recv_dev, "allgather_logits: null pointer");
+  const RcclEntry& e = rccl_entry();
+  DH_REQUIRE(e.allgather, "allgather_logits: %s", e.why ? e.why : "RCCL not found");
+  const int rc = e.allgather(send_dev, recv_dev, (size_t)n_per_rank * (size_t)n_cls, /* ncclFloat32 */ 7, comm, dh::as_stream(stream));
+  if (rc != 0) {
+    dh::set_error("allgather_logits: ncclAllGather failed: %s (%d)", e.errstr ? e.errstr(rc) : "?", rc);
+    return DH_EHIP;
+  }
+  return DH_OK;
+}

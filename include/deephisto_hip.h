@@ -111,6 +111,19 @@ int dh_accumulate_logits(const float* logits_dev, const int32_t* yx_host, int64_
 int dh_argmax_map(const float* canvas_dev, int64_t n_cells, int32_t n_cls, int64_t* map_dev,
                   void* stream);
 
+/* ---- e1: the exchange step of the tile-sharded prediction -------------------------------
+ * The reference predicts every tile on one device and sums the logits into the canvas in list order
+ * (examples/predict_full_patched.py:40-63).  Sharded over ranks each rank predicts a
+ * contiguous range of that list; this call is the ONE exchange: every rank contributes
+ * float32[n_per_rank][n_cls] (ranges padded to a common length by the caller) and receives
+ * float32[world][n_per_rank][n_cls] in rank order, after which each rank runs dh_accumulate_logits on the
+ * whole list.  comm: the caller's RCCL communicator (ncclComm_t), created by the caller with the RCCL of
+ * its process; RCCL is resolved from the process at the first call (librccl.so.1, or DH_RCCL_LIB) -- this
+ * library does not link against it.  Asynchronous on `stream`.  The Python shims exchange through
+ * torch.distributed instead (examples/predict_full_patched.py: exchange_logits). */
+int dh_allgather_logits(void* comm, const float* send_dev, float* recv_dev, int64_t n_per_rank,
+                        int32_t n_cls, void* stream);
+
 /* ---- visualisation of the class map (examples/predict_full_patched.py:81-113) ----
  * dh_colorize_map: `colored[pred == anno.id] = anno.color` for every class (:93-95):
  *   rgb[i] = lut[map[i]] when 0 <= map[i] < n_cls, else (0,0,0); lut = uint8[n_cls][3] on the device.

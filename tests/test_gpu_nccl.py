@@ -76,3 +76,49 @@ def test_rccl_calls_on_one_rank(built_lib):
     assert p.exitcode == 0
     assert out["gather"] and out["arena"] and out["arena18"], out
     assert out["buckets"] == [0, 1, 2, 3]
+
+
+def _worker_cabi(q):
+    """The C-ABI exchange entry the way a host that is not a torch.distributed program calls it: an RCCL communicator of its own."""
+    import ctypes as C
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from deephisto_amd._lib import lib
+    out = {}
+    rccl = C.CDLL("librccl.so.1")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    uid = UniqueId()
+    out["uid"] = rccl.ncclGetUniqueId(C.byref(uid))
+    comm = C.c_void_p()
+    out["init"] = rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0)
+    send = torch.randn(4802, 5, device=dev)
+    recv = torch.zeros_like(send)
+    st = torch.cuda.current_stream().cuda_stream
+    out["rc"] = lib().dh_allgather_logits(comm, send.data_ptr(), recv.data_ptr(), 4802, 5, st)
+    torch.cuda.synchronize()
+    out["equal"] = bool(torch.equal(send, recv))          # one rank: the gathered list is the rank's own
+    out["null_comm"] = lib().dh_allgather_logits(None, send.data_ptr(), recv.data_ptr(), 4802, 5, st)
+    out["null_ptr"] = lib().dh_allgather_logits(comm, None, recv.data_ptr(), 4802, 5, st)
+    out["empty"] = lib().dh_allgather_logits(comm, None, None, 0, 5, st)
+    rccl.ncclCommDestroy(comm)
+    q.put(out)
+
+
+def test_c_abi_allgather_on_one_rank(built_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_cabi, args=(q,))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert out["uid"] == 0 and out["init"] == 0, out
+    assert out["rc"] == 0 and out["equal"], out
+    assert out["null_comm"] == -22 and out["null_ptr"] == -22 and out["empty"] == 0, out
