@@ -77,3 +77,23 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
     with pytest.raises(_lib.DeephistoHipError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_tile_grid_property_against_the_pinned_oracle(built_lib):
+    """Random ragged geometries (non-divisible sizes, stride != patch, every padding length incl. none): the host entry of the C ABI ==
+    oracle/tiling.py, which is pinned to the reference's own `_create_batched_coords` output by the fixtures above (full_samplers.py:331-352)."""
+    from hypothesis import given, settings, strategies as st
+    from deephisto_amd import tiles
+    from oracle import tiling
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 64), st.integers(1, 64), st.integers(0, 700), st.integers(0, 700), st.integers(1, 9))
+    def check(patch8, stride8, eh, ew, batch):
+        patch, stride = 8 * patch8, 8 * stride8
+        h, w = patch + eh, patch + ew
+        want = tiling.batched_origins(h, w, patch, stride, batch).reshape(-1, 2)   # the C entry returns the padded list, un-batched
+        got, n_unique = tiles.tile_grid(h, w, patch, stride, batch)
+        assert n_unique == len(tiling.tile_origins(h, w, patch, stride))
+        assert got.dtype == np.int32 and got.shape == want.shape and np.array_equal(got, want)
+
+    check()
