@@ -14,6 +14,11 @@ torchvision's initialisation (Kaiming-normal fan_out for convs, BN weight 1 /
 bias 0, nn.Linear default for fc).  Anchors: model.py:5-11 (factory),
 train.py:117-118,166-172 (CrossEntropyLoss mean, Adam lr, step order),
 examples/predict_full_patched.py:66-78 (inference: raw logits, no softmax).
+
+Cross-check (round 4): tests/test_oracle_crosscheck.py copies this model's parameters and running statistics into Hugging Face
+transformers' `ResNetModel` (5.15.0, installed offline; an independently written implementation of the same published
+architecture) and requires equal eval logits, training-mode logits, running statistics and parameter gradients to float32
+round-off.  That is evidence for the restatement, not the reference's own dependency: "parity unpinned" stands.
 """
 from __future__ import annotations
 

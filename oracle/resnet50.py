@@ -10,6 +10,11 @@ global average pool; linear head) with `torch.nn` primitives, the same `state_di
 (`layer2.0.conv3.weight`, `layer2.0.downsample.1.running_var`, ...) and torchvision's initialisation
 (Kaiming-normal fan_out for convs, BN weight 1 / bias 0, nn.Linear default for fc; zero_init_residual off).
 23 518 277 parameters at n_classes = 5.  Step semantics: train.py:117-118, 166-172.
+
+Cross-check (round 4): tests/test_oracle_crosscheck.py copies this model's parameters and running statistics into Hugging Face
+transformers' `ResNetModel` (5.15.0, installed offline; an independently written implementation of the same published
+architecture) and requires equal eval logits, training-mode logits, running statistics and parameter gradients to float32
+round-off.  That is evidence for the restatement, not the reference's own dependency: "parity unpinned" stands.
 """
 from __future__ import annotations
 
