@@ -23,8 +23,13 @@ path (NumPy tiling + torch-CPU ResNet-18 fp32) timed on a bounded sample; and, a
   `train_r50`  BASELINE configs[4] per-rank work: ResNet-50 bf16 training steps/s at 64 x 224^2 vs the bf16 MFMA peak;
   `tiler`      the stand-alone gather kernels (a4 path) in GB/s against the 8 TB/s HBM peak;
   `cpu_baselines` sampler-only `generator_torch` (one process, as INMEMORY_SINGLEPROC) and a CPU train step, each with cores.
-At N > 1 the line also carries `train_ddp`: ResNet-50 bf16 data-parallel steps/s with the bucketed, overlapped RCCL
-all-reduce (configs[4]); a failure there is reported in the object and never costs the headline number.
+  `p224`       the reference's OWN geometry (examples/predict_full_patched.py:157-167, config.yaml:23): the same slide at 224 x 224 tiles,
+               stride 112 (198 916 tiles), patches/s, whole-model fraction at 3.6271 GFLOP per tile, dominant-kernel roofline.
+At N > 1 the line also carries `ranks` (what RCCL saw: rank, device index, PCI bus id / uuid and tile range of every rank, gathered over
+the group), `backend`, `nccl_version`, `allgather_ms`, and `train_ddp`: ResNet-50 bf16 data-parallel steps/s with the bucketed RCCL all-reduce
+(configs[4]) overlapped with the backward pass AND (`overlap_off`) exchanged after it -- the difference shows whether RCCL's kernels got CUs beside
+the persistent convolutions.  A failure in that leg is reported in the object; the ranks agree on it through the rendezvous store (never through a
+collective a failed rank may no longer take part in) before anyone enters the closing barrier.
 """
 from __future__ import annotations
 
@@ -69,6 +74,7 @@ def parse():
                     help="extra legs: time this many fused training steps (configs[1] f32 ResNet-18, configs[4] bf16 ResNet-50); 0 = skip")
     ap.add_argument("--f32-steps", type=int, default=2, help="extra leg: whole slides in float32 (0 = skip)")
     ap.add_argument("--no-extra-legs", action="store_true", help="headline measurement only (profiling runs)")
+    ap.add_argument("--p224-steps", type=int, default=2, help="extra leg: whole slides at the reference's 224 / 112 geometry (0 = skip)")
     return ap.parse_args()
 
 
@@ -352,10 +358,12 @@ def main():
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
+        from deephisto_amd.distributed import dist_timeout
+        # explicit collective timeout (DH_DIST_TIMEOUT_S, default 600 s): a stuck peer ends the job instead of holding it for the backend's default
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=dist_timeout())
         else:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=dev, timeout=dist_timeout())  # RCCL over xGMI
 
     from deephisto_amd import tiles
     from deephisto_amd._lib import check, lib
@@ -380,10 +388,10 @@ def main():
 
     exchange_events: list = []   # (start, end) HIP events around every all-gather of the timed region (world > 1)
 
-    def timed_predict(mdl, steps, warmup, micro_batch=None):
+    def timed_predict(mdl, steps, warmup, micro_batch=None, sampler=None):
         """(elapsed seconds for `steps` whole slides, dominant-kernel ms / flops / samples over the timed region, class map)"""
         def step():
-            return predict_full_patched(smp, mdl, 5, downscale=args.downscale, micro_batch=micro_batch or args.micro_batch, streams=args.streams,
+            return predict_full_patched(sampler or smp, mdl, 5, downscale=args.downscale, micro_batch=micro_batch or args.micro_batch, streams=args.streams,
                                         timing=exchange_events)
         for _ in range(warmup):
             step()
@@ -407,6 +415,18 @@ def main():
     elapsed = float(t.item())
     assert cmap.shape == (side // args.downscale, side // args.downscale)
 
+    # what RCCL saw (N > 1): every rank's device and tile range, gathered over the group itself
+    ranks_seen = None
+    if world > 1:
+        from deephisto_amd.examples.predict_full_patched import shard_range
+        props = torch.cuda.get_device_properties(dev_index)
+        lo, hi = shard_range(n_tiles, world, rank)
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None,
+                "tile_lo": lo, "tile_hi": hi, "pid": os.getpid()}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, mine)
+
     # configs[4] under torch.distributed: ResNet-50 bf16 data-parallel steps (every rank takes part; reported by rank 0)
     allgather_ms = None
     if world > 1 and exchange_events:
@@ -416,6 +436,8 @@ def main():
         try:
             del slide, smp
             torch.cuda.empty_cache()
+            if os.environ.get("DH_BENCH_FAIL_DDP") == "1":   # test hook: the leg fails on every rank before its first collective
+                raise RuntimeError("DH_BENCH_FAIL_DDP=1: injected failure of the train_ddp leg")
             # the same per-rank step three ways: gradients exchanged in float32 (default wire), in bf16 (half the bytes per xGMI
             # link), and not exchanged at all -- the difference is what the bucketed, overlapped all-reduce leaves exposed
             os.environ["DH_DDP_WIRE"] = "f32"
@@ -423,21 +445,47 @@ def main():
             os.environ["DH_DDP_WIRE"] = "bf16"
             leg_bf16 = train_leg(dev, args.train_steps, "resnet50", "bf16", group=dist.group.WORLD)
             os.environ["DH_DDP_WIRE"] = "f32"
+            # the same buckets exchanged AFTER the backward pass (DH_DDP_OVERLAP=0; bit-equal gradients): if this is not slower than the
+            # overlapped step, RCCL's kernels did not get CUs beside the persistent convolution kernels and the overlap hides nothing
+            os.environ["DH_DDP_OVERLAP"] = "0"
+            leg_late = train_leg(dev, args.train_steps, "resnet50", "bf16", group=dist.group.WORLD)
+            os.environ["DH_DDP_OVERLAP"] = "1"
             solo = [dist.new_group([r]) for r in range(world)][rank]   # a group of this rank alone: train_step sees world = 1, no exchange
             local = train_leg(dev, args.train_steps, "resnet50", "bf16", group=solo)
             lm = torch.tensor([local["ms_per_step"]], dtype=torch.float64, device=dev)
             dist.all_reduce(lm, op=dist.ReduceOp.MAX)     # the slowest rank's un-exchanged step
             train_ddp["local_step_ms"] = float(lm.item())
             train_ddp["allreduce_exposed_ms"] = train_ddp["ms_per_step"] - float(lm.item())
+            train_ddp["overlap_off"] = {"steps_per_s": leg_late["steps_per_s"], "ms_per_step": leg_late["ms_per_step"],
+                                        "allreduce_exposed_ms": leg_late["ms_per_step"] - float(lm.item()),
+                                        "note": "DH_DDP_OVERLAP=0: same buckets, one after the other, after the backward pass"}
             train_ddp["wire_bf16"] = {"steps_per_s": leg_bf16["steps_per_s"], "ms_per_step": leg_bf16["ms_per_step"],
                                       "allreduce_exposed_ms": leg_bf16["ms_per_step"] - float(lm.item()),
                                       "parallelism": leg_bf16["config"].get("parallelism")}
         except Exception as e:   # never costs the headline number
             err = {"error": f"{type(e).__name__}: {e}"[:400]}
             train_ddp = dict(train_ddp, **err) if isinstance(train_ddp, dict) else err
-    if world > 1:   # every collective is done: the ranks part here, rank 0 goes on to the CPU baseline alone
-        dist.barrier()
-        dist.destroy_process_group()
+    stuck = None
+    if world > 1:
+        # Agree on how the leg ended BEFORE any further collective: a rank that failed inside the leg has left collectives
+        # its peers may still be waiting in, so a barrier here could mismatch and block until the backend timeout.  The agreement goes
+        # through the rendezvous store (host side, no GPU, bounded wait): when every rank has checked in, nobody is inside a collective
+        # and the barrier is safe; when some rank does not arrive, rank 0 still prints its line and everybody leaves non-zero.
+        store = dist.distributed_c10d._get_default_store()
+        my_err = train_ddp.get("error") if isinstance(train_ddp, dict) else None
+        store.set(f"bench/leg_done/{rank}", my_err or "ok")
+        from datetime import timedelta
+        try:
+            store.wait([f"bench/leg_done/{r}" for r in range(world)], timedelta(seconds=float(os.environ.get("DH_BENCH_AGREE_S", "120"))))
+            states = [store.get(f"bench/leg_done/{r}").decode() for r in range(world)]
+            bad = {r: st for r, st in enumerate(states) if st != "ok"}
+            if bad and isinstance(train_ddp, dict) and "error" not in train_ddp:
+                train_ddp["error"] = f"rank(s) {sorted(bad)} failed: {next(iter(bad.values()))}"[:400]
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:   # some rank never left the leg
+            stuck = f"{type(e).__name__}: not every rank finished the train_ddp leg: {e}"[:300]
+            train_ddp = dict(train_ddp or {}, error=stuck)
 
     if rank == 0:
         value = args.steps * n_tiles / elapsed
@@ -491,6 +539,24 @@ def main():
                                        "frac": a32 / MFMA_PEAK_TFLOPS["f32"], "launches_timed": kn,
                                        "avg_launch_us": 1e3 * kms / max(1, kn)}}
             del m32
+        if extra and args.p224_steps > 0 and args.dtype == "bf16" and (args.patch, args.stride) != (224, 112):
+            # the reference's own call sites tile 224 x 224 at stride 112 (examples/predict_full_patched.py:157-167, config.yaml:23)
+            with contextlib.redirect_stdout(sys.stderr):
+                smp224 = FullImageDenseSampler(slide, layer=1, patch_size=224, batch_size=args.batch, stride=112, device=dev)
+            el, kms, kfl, kn, cm224 = timed_predict(model, args.p224_steps, 1, sampler=smp224)
+            assert cm224.shape == (side // args.downscale, side // args.downscale)
+            v224 = args.p224_steps * smp224.n_tiles / el
+            f224 = 3.6271e9                                  # FLOP per 224^2 tile
+            a224 = (kfl / (kms * 1e-3)) / 1e12 if kms > 0 else 0.0
+            out["p224"] = {"value": v224, "unit": "patches/s", "steps": args.p224_steps, "ms_per_step": 1e3 * el / args.p224_steps,
+                           "config": {"workload": f"predict_full_patched on the same {side}x{side} slide at the reference's geometry: 224x224 tiles, "
+                                                  "stride 112 (examples/predict_full_patched.py:157-167)", "patch": 224, "stride": 112,
+                                      "n_tiles": smp224.n_tiles, "micro_batch": args.micro_batch},
+                           "model_tflops": v224 * f224 / 1e12, "model_frac": v224 * f224 / 1e12 / peak, "flop_per_tile": f224,
+                           "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel<bf16, stride 1> at 56 / 28 / 14-pixel maps (the launches the library samples as dominant)",
+                                        "achieved": a224, "peak": peak, "unit": "TFLOP/s", "frac": a224 / peak, "launches_timed": kn,
+                                        "avg_launch_us": 1e3 * kms / max(1, kn), "flops_per_launch": kfl / max(1, kn)}}
+            del smp224
         if extra:
             out["tiler"] = tiler_leg(dev, slide, args)
         if extra and args.train_steps > 0:
@@ -500,6 +566,13 @@ def main():
             out["train_bf16"] = train_leg(dev, args.train_steps, "resnet18", "bf16")   # the same network on the bf16 engine (f32 masters)
             out["train_r50"] = train_leg(dev, args.train_steps, "resnet50", "bf16")
         if world > 1:
+            out["ranks"] = ranks_seen            # gathered over the group: what RCCL saw (device per rank, tile range per rank)
+            out["backend"] = "gloo (DH_BENCH_SHARE_GPU rehearsal: every rank on cuda:0)" if share else "nccl (RCCL)"
+            try:
+                out["nccl_version"] = ".".join(map(str, torch.cuda.nccl.version()))
+            except Exception:
+                out["nccl_version"] = None
+            out["distinct_devices"] = len({(r or {}).get("pci_bus_id") or (r or {}).get("uuid") or (r or {}).get("device") for r in ranks_seen})
             out["allgather_ms"] = allgather_ms   # HIP-event time of the ONE RCCL all-gather of per-tile logits, mean per slide (rank 0)
             out["train_ddp"] = train_ddp
         if not args.no_cpu_baseline:
@@ -511,6 +584,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if stuck is not None:   # a rank is still inside a collective: leave without one, non-zero, so that the launcher ends the job now
+        sys.stderr.write(f"[bench rank {rank}] {stuck}\n")
+        sys.stderr.flush()
+        os._exit(3)
 
 
 if __name__ == "__main__":

@@ -36,6 +36,7 @@ SIGNATURES = {
     "dh_tile_gather_raw": (C.c_int, [_p, _i64, _i64, _p, _i64, _i32, _p, _p]),
     "dh_tile_coords_f32": (C.c_int, [_p, _i64, _p, _p]),
     "dh_accumulate_logits": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i64, _i64, _p, _p, _p]),
+    "dh_set_rccl": (C.c_int, [_p]),
     "dh_allgather_logits": (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
     "dh_argmax_map": (C.c_int, [_p, _i64, _i32, _p, _p]),
     "dh_colorize_map": (C.c_int, [_p, _i64, _p, _i32, _p, _p]),
@@ -99,6 +100,7 @@ DEBUG_SIGNATURES = {
     "dh_debug_maxpool_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_bn_pool_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_stamps": (C.c_int, [_i32, _p]),
+    "dh_debug_env_knobs": (C.c_int, [C.c_char_p, _i64]),
 }
 
 

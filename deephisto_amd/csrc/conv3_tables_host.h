@@ -98,6 +98,18 @@ template <int STRIDE, int NT, int WAVES, int ESZ, int MT, class P, bool HALF = f
 const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out) {
   constexpr int MAXJ = max_window_pieces<STRIDE, NT, WAVES>();
   const int threads = WAVES * 64, stride = 3 * NT + MAXJ;
+  // Invariants the KERNEL relies on and cannot check, stated where its addresses are made:
+  //  * at least two channel stages per tile: the mask word of the NEXT tile is fetched by the cursor step that enters the second stage
+  //    of the current one (conv3x3.inc, `if (L_ch == 1) fetch_mask()`); with a single stage every tile after the first would reuse tile
+  //    0's mask -- wrong padding and out-of-image DMA sources;
+  //  * the staged window fits 64 KiB: the hoisted per-lane fragment offsets are kept as 16-bit halves (conv3x3.inc, HOIST), and a DMA
+  //    instruction lands 1 KiB, so n_win_instr KiB must cover the window and stay <= 64;
+  //  * a descriptor word holds the cout block in bits 0-15, `valid` in bit 16 and the mask row in bits 20-31.
+  constexpr int STAGE_PX_BYTES = HALF ? kChunkBytes / 2 : kChunkBytes;
+  if ((int64_t)p.Cin * ESZ < 2 * STAGE_PX_BYTES || ((int64_t)p.Cin * ESZ) % STAGE_PX_BYTES) return "conv3x3: needs at least two whole channel stages per tile";
+  if ((int64_t)p.IMGS * p.HR * p.HP * STAGE_PX_BYTES > 65536) return "conv3x3: staged window larger than 64 KiB (16-bit fragment offsets)";
+  if ((int64_t)p.n_win_instr * 1024 < (int64_t)p.IMGS * p.HR * p.HP * STAGE_PX_BYTES) return "conv3x3: the DMA plan does not cover the staged window";
+  if (ncb < 1 || ncb > 65535) return "conv3x3: cout block count does not fit the descriptor word";
   std::vector<int>& lane = out->lane;
   lane.assign((size_t)threads * stride, 0);
   // per-thread geometry kept for the mask rows below: output pixel (ty, tx, img) per n-tile, window piece (hy, hx, img, live)
@@ -207,7 +219,8 @@ const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out
       const int64_t out_off = (int64_t)img0 * p.o_img + (int64_t)oy0 * p.o_row + (int64_t)ox0 * p.o_px + p.o_base + (int64_t)cb * p.out_cb;
       const int64_t res_off = (int64_t)img0 * p.o_img + (int64_t)oy0 * p.r_row + (int64_t)ox0 * p.r_px + p.r_base + (int64_t)cb * p.r_cb;
       if (win_off >= ((int64_t)1 << 32) || out_off >= ((int64_t)1 << 32) || res_off >= ((int64_t)1 << 32)) return "conv3x3: tensor larger than 4 Gi elements / bytes";
-      tile[(size_t)it * grid + w] = TileDesc{cb | (valid << 16) | (mrow << 20), (int)(uint32_t)win_off, (int)(uint32_t)out_off, (int)(uint32_t)res_off};
+      const uint32_t word = (uint32_t)cb | (uint32_t)valid << 16 | (uint32_t)mrow << 20;   // unsigned: mask rows >= 2048 reach bit 31
+      tile[(size_t)it * grid + w] = TileDesc{(int)word, (int)(uint32_t)win_off, (int)(uint32_t)out_off, (int)(uint32_t)res_off};
     }
   out->grid = grid; out->threads = threads; out->lane_stride = stride; out->mask_rows = (int)mask_row.size(); out->xcd_group = xcd_group;
   return nullptr;

@@ -14,6 +14,13 @@ void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Run-time switches: the table of env_knobs.h is the only way the library reads the environment (besides DH_RCCL_LIB, a path).
+// env_int: the variable's value, or the knob's default when unset or unparsable (then recorded: env_check fails from then on).
+// env_check: validates EVERY knob of the table now; DH_EINVAL + dh_last_error() naming the first bad variable.  Called by the
+// create entry points, so a mistyped value stops a run before its first kernel instead of being atoi'd into something else.
+int env_int(const char* name);
+int env_check();
+
 }  // namespace dh
 
 #define DH_REQUIRE(cond, ...)            \

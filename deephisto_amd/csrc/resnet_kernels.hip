@@ -814,7 +814,7 @@ int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
 // Will a 3x3 / stride-2 conv + fused downsample of this shape run on the wide kernel (conv3x3.inc, HALF)?  Then its INPUT must be written in
 // 16-channel planes by the conv before it (forward_impl decides with this before launching that conv).
 inline bool s2_wide_eligible(const ConvLayer& c1, const ConvLayer& ds, int esz, int Wo) {
-  static const bool on = !(getenv("DH_CONV_S2_WIDE") && atoi(getenv("DH_CONV_S2_WIDE")) == 0);
+  static const bool on = dh::env_int("DH_CONV_S2_WIDE") != 0;
   return on && esz == 2 && c1.w2_dev && ds.w2_dev && c1.cout % 128 == 0 && Wo > 4;
 }
 
@@ -885,7 +885,7 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     int variant;  // 0: NT=2 MT=2 (512 px)   1: NT=1 MT=2 (256 px)   2: NT=1 MT=1 (128 px)
     // candidates from the largest tile down; the first that gives every CU a tile wins, else the smallest (round 3: a launch
     // with few pixels -- a parity class of a stride-2 data gradient at batch 64 -- used to run 512-pixel tiles on half the chip)
-    static const int min_tiles = getenv("DH_CONV_MIN_TILES") ? atoi(getenv("DH_CONV_MIN_TILES")) : 256;
+    constexpr int min_tiles = 256;
     const dh_conv3::Cand cd = dh_conv3::pick_stride1(B, Ho, Wo, L.cout, min_tiles);   // conv3_tables_host.h
     dh_conv3::set_stride1_geometry(p, cd, Ho, Wo);
     variant = cd.variant;
@@ -905,7 +905,7 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
   } else {
     // round 4: the wide variant (128 couts x 256 pixels per workgroup on half-chunk stages; conv3x3.inc, HALF) where its packing exists
     // (bf16 inference, fused downsample, cout % 128 == 0) and the map is at least 16 pixels wide.  DH_CONV_S2_WIDE=0: the 128-pixel kernel
-    static const bool s2_wide = !(getenv("DH_CONV_S2_WIDE") && atoi(getenv("DH_CONV_S2_WIDE")) == 0);
+    static const bool s2_wide = dh::env_int("DH_CONV_S2_WIDE") != 0;
     if constexpr (sizeof(T) == 2) {
       if (in16) {
         DH_REQUIRE(s2_wide && ds && blocked && L.w2_dev && ds->w2_dev && L.cout % 128 == 0 && dh_conv3::set_stride2_wide_geometry(p, Ho, Wo),
@@ -990,22 +990,13 @@ int launch_dgrad_s2_merged_cfg(Conv3Params (&pc)[4], const int (&tiles_c)[4], co
 // parity class of the dX pixel (1, 2, 2 and 4 taps of the flipped + transposed operator `L.w_dev`; conv3x3.inc, CLS), side by side in ONE
 // launch (conv3x3_s2dgrad_kernel).  dz is [B][Ho][Wo][L.cin], dx (and res, the gradient joining from another branch, may be null)
 // [B][Hi][Wi][L.cout], NHWC.  (History: four launches on one stream -- each fills a fraction of the chip at batch 64; four streams forked
-// and joined by events -- slower still, 9.64 -> 10.63 ms per float32 step.  DH_DGRAD_S2_SERIAL=1 keeps the four launches for A/B.)
+// and joined by events -- slower still, 9.64 -> 10.63 ms per float32 step.)
 template <typename T>
 int launch_dgrad_s2(const ConvLayer& L, const void* dz, const void* res, void* dx, int B, int Ho, int Wo, int Hi, int Wi, hipStream_t st) {
   DH_REQUIRE(Ho == (Hi + 2 - 3) / 2 + 1 && Wo == (Wi + 2 - 3) / 2 + 1, "dgrad s2: %dx%d is not the stride-2 output of %dx%d", Ho, Wo, Hi, Wi);
   int rc;
   const int re = (Hi + 1) / 2, ro = Hi / 2, ce = (Wi + 1) / 2, co = Wi / 2;   // rows / columns of dX with even / odd index
-  static const bool serial = getenv("DH_DGRAD_S2_SERIAL") != nullptr;
-  if (serial) {
-    if (ro > 0 && co > 0 && (rc = launch_conv3x3<T, 1, 3>(L, dz, res, dx, B, Ho, Wo, false, st, ro, co, nullptr, nullptr, false, Hi, Wi))) return rc;
-    if (re > 0 && co > 0 && (rc = launch_conv3x3<T, 1, 1>(L, dz, res, dx, B, Ho, Wo, false, st, re, co, nullptr, nullptr, false, Hi, Wi))) return rc;
-    if (ro > 0 && ce > 0 && (rc = launch_conv3x3<T, 1, 2>(L, dz, res, dx, B, Ho, Wo, false, st, ro, ce, nullptr, nullptr, false, Hi, Wi))) return rc;
-    if (re > 0 && ce > 0 && (rc = launch_conv3x3<T, 1, 0>(L, dz, res, dx, B, Ho, Wo, false, st, re, ce, nullptr, nullptr, false, Hi, Wi))) return rc;
-    return DH_OK;
-  }
-  static const bool per_class = getenv("DH_DGRAD_S2_MERGED") != nullptr;   // A/B: the merged class launch instead of the all-classes kernel
-  if (!per_class && Hi % 2 == 0 && Wi % 2 == 0) {
+  if (Hi % 2 == 0 && Wi % 2 == 0) {
     // all four classes from one staged dZ window (conv3x3.inc, CLS == 4): a stride-1 convolution over the dZ grid with four accumulator
     // sets; 256- or 128-pixel tiles (NT = 1)
     Conv3Params p;
@@ -1266,6 +1257,7 @@ extern "C" int dh_resnet18_create(dh_resnet18** out, int32_t n_classes, int32_t 
   DH_REQUIRE(out != nullptr, "resnet18 create: null output");
   DH_REQUIRE(n_classes > 0 && n_classes <= 1024, "resnet18 create: n_classes=%d", n_classes);
   DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "resnet18 create: bad dtype %d", dtype);
+  if (int erc = dh::env_check()) return erc;   // a mistyped DH_* switch stops here, named by dh_last_error()
   auto* net = new dh_resnet18();
   net->n_classes = n_classes;
   net->dtype = dtype;

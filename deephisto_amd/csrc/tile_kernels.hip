@@ -5,13 +5,16 @@
 //   a8  dh_accumulate_logits    ordered (bit-exact) canvas accumulation, dh_argmax_map
 // All of these are HBM-bound byte/integer work: no LDS, no MFMA; the design
 // rules are full-width coalesced rows (one wave = one tile row) and 16-byte stores.
+#include <errno.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <vector>
 
 #include "dh_common.h"
+#include "env_knobs.h"
 
 namespace dh {
 static thread_local std::string g_err;
@@ -24,6 +27,65 @@ void set_error(const char* fmt, ...) {
   g_err = buf;
 }
 }  // namespace dh
+
+namespace dh {
+namespace {
+struct EnvKnob { const char* name; long def, lo, hi; const char* read; const char* effect; };
+#define DH_ENV_ROW(n, d, l, h, r, e) {#n, (long)(d), (long)(l), (long)(h), r, e},
+const EnvKnob g_env_knobs[] = {DH_ENV_KNOBS(DH_ENV_ROW)};
+#undef DH_ENV_ROW
+// 0: unset (default), 1: valid (*out), -1: set but not a decimal integer in [lo, hi]
+int env_parse(const EnvKnob& k, long* out) {
+  const char* v = getenv(k.name);
+  *out = k.def;
+  if (!v) return 0;
+  char* end = nullptr;
+  errno = 0;
+  const long x = strtol(v, &end, 10);
+  if (end == v || *end != '\0' || errno != 0 || x < k.lo || x > k.hi) return -1;
+  *out = x;
+  return 1;
+}
+void env_complain(const EnvKnob& k) {
+  set_error("%s='%s' is not an integer in [%ld, %ld] (default %ld): %s", k.name, getenv(k.name), k.lo, k.hi, k.def, k.effect);
+}
+}  // namespace
+
+int env_int(const char* name) {
+  for (const EnvKnob& k : g_env_knobs)
+    if (!strcmp(k.name, name)) {
+      long v;
+      if (env_parse(k, &v) < 0) {
+        env_complain(k);
+        fprintf(stderr, "libdeephisto_hip: %s -- default used\n", g_err.c_str());
+      }
+      return (int)v;
+    }
+  fprintf(stderr, "libdeephisto_hip: internal error: environment knob %s is not in env_knobs.h\n", name);
+  abort();
+}
+
+int env_check() {
+  for (const EnvKnob& k : g_env_knobs) {
+    long v;
+    if (env_parse(k, &v) < 0) { env_complain(k); return DH_EINVAL; }
+  }
+  return DH_OK;
+}
+}  // namespace dh
+
+// test hook: the table of env_knobs.h as text, one "NAME default lo hi read" line per knob (INTEGRATION.md carries the same table)
+extern "C" int dh_debug_env_knobs(char* buf, int64_t cap) {
+  std::string s;
+  char line[256];
+  for (const dh::EnvKnob& k : dh::g_env_knobs) {
+    snprintf(line, sizeof line, "%s %ld %ld %ld %s\n", k.name, k.def, k.lo, k.hi, k.read);
+    s += line;
+  }
+  DH_REQUIRE(buf && (int64_t)s.size() + 1 <= cap, "dh_debug_env_knobs: buffer of %lld bytes too small (%zu needed)", (long long)cap, s.size() + 1);
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return DH_OK;
+}
 
 extern "C" int dh_abi_version(void) { return 1; }
 extern "C" const char* dh_last_error(void) { return dh::g_err.c_str(); }
@@ -578,47 +640,75 @@ extern "C" int dh_overlay_blend(const uint8_t* img, const uint8_t* col, int64_t 
 // ---------------------------------------------------------------------------
 // e1: the one exchange step of the sharded whole-slide prediction (every rank contributes the logits of its
 // contiguous tile range, every rank receives all of them) as a C-ABI entry for hosts that are not torch.distributed programs.
-// `comm` is the caller's ncclComm_t (RCCL); RCCL is resolved at the first call from the process image -- the library the caller
-// created `comm` with -- so that this shared object carries no link-time dependency on it (the Python shims exchange through
-// torch.distributed, whose RCCL never gets here).  DH_RCCL_LIB names another file to load.
+// `comm` is the caller's ncclComm_t (RCCL).  The ncclAllGather that is called MUST come from the library instance that created `comm`
+// (a second copy of RCCL handed a foreign communicator corrupts memory or hangs: ADVICE r4), so this shared object neither links
+// against RCCL nor loads one on its own account.  Resolution order at the first exchange:
+//   1. dh_set_rccl(handle): the host passes the dlopen handle of ITS RCCL (the exact answer; required when that copy was loaded
+//      RTLD_LOCAL under a private path, e.g. a bundled torch/lib/librccl.so);
+//   2. DH_RCCL_LIB=<file>: that file, which must ALREADY be loaded in the process (RTLD_NOLOAD probe; otherwise an error);
+//   3. a global ncclAllGather symbol (RTLD_DEFAULT), then librccl.so.1 / librccl.so if already loaded (RTLD_NOLOAD).
+// Nothing already loaded => DH_EINVAL: a process without RCCL cannot own a communicator.  (The Python shims exchange through
+// torch.distributed, whose RCCL never gets here.)  rccl.h is included for ncclFloat32 / ncclResult_t only: no symbol is linked.
 // ---------------------------------------------------------------------------
 #include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <mutex>
 namespace {
-typedef int (*rccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
-typedef const char* (*rccl_errstr_fn)(int);
-struct RcclEntry { rccl_allgather_fn allgather = nullptr; rccl_errstr_fn errstr = nullptr; const char* why = nullptr; };
-const RcclEntry& rccl_entry() {
-  static const RcclEntry e = [] {
-    RcclEntry r;
-    void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");      // an RCCL with global symbols is already in the process
-    void* h = nullptr;
-    if (!sym) {
-      const char* names[3] = {getenv("DH_RCCL_LIB"), "librccl.so.1", "librccl.so"};   // by SONAME: glibc hands back a copy that is already loaded
-      for (const char* nm : names) {
-        if (!nm || !*nm) continue;
-        if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
-      }
-      if (h) sym = dlsym(h, "ncclAllGather");
-    }
-    if (!sym) { r.why = "RCCL not found (librccl.so.1; set DH_RCCL_LIB)"; return r; }
+typedef ncclResult_t (*rccl_allgather_fn)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+typedef const char* (*rccl_errstr_fn)(ncclResult_t);
+struct RcclEntry { rccl_allgather_fn allgather = nullptr; rccl_errstr_fn errstr = nullptr; std::string why; bool resolved = false; };
+std::mutex g_rccl_mu;
+RcclEntry g_rccl;
+void rccl_from_handle(RcclEntry& r, void* h, const char* what) {
+  void* sym = dlsym(h, "ncclAllGather");
+  if (!sym) { r.why = std::string(what) + " has no ncclAllGather"; return; }
+  r.allgather = reinterpret_cast<rccl_allgather_fn>(sym);
+  r.errstr = reinterpret_cast<rccl_errstr_fn>(dlsym(h, "ncclGetErrorString"));
+}
+void rccl_resolve(RcclEntry& r) {
+  r.resolved = true;
+  if (const char* nm = getenv("DH_RCCL_LIB"); nm && *nm) {
+    void* h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    if (!h) { r.why = std::string("DH_RCCL_LIB=") + nm + " is not loaded in this process (the communicator's own library must be named)"; return; }
+    rccl_from_handle(r, h, nm);
+    return;
+  }
+  if (void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather")) {
     r.allgather = reinterpret_cast<rccl_allgather_fn>(sym);
-    r.errstr = reinterpret_cast<rccl_errstr_fn>(h ? dlsym(h, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
-    return r;
-  }();
-  return e;
+    r.errstr = reinterpret_cast<rccl_errstr_fn>(dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    return;
+  }
+  for (const char* nm : {"librccl.so.1", "librccl.so"})
+    if (void* h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD)) { rccl_from_handle(r, h, nm); return; }
+  r.why = "no RCCL is loaded in this process (pass the handle of the communicator's library with dh_set_rccl, or name it in DH_RCCL_LIB)";
 }
 }  // namespace
+
+extern "C" int dh_set_rccl(void* dl_handle) {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  g_rccl = RcclEntry();
+  if (!dl_handle) return DH_OK;   // back to automatic resolution at the next exchange
+  g_rccl.resolved = true;
+  rccl_from_handle(g_rccl, dl_handle, "the handle given to dh_set_rccl");
+  DH_REQUIRE(g_rccl.allgather, "dh_set_rccl: %s", g_rccl.why.c_str());
+  return DH_OK;
+}
 
 extern "C" int dh_allgather_logits(void* comm, const float* send_dev, float* recv_dev, int64_t n_per_rank, int32_t n_cls, void* stream) {
   DH_REQUIRE(comm, "allgather_logits: null communicator");
   DH_REQUIRE(n_per_rank >= 0 && n_cls > 0, "allgather_logits: bad sizes");
   if (n_per_rank == 0) return DH_OK;
   DH_REQUIRE(send_dev && recv_dev, "allgather_logits: null pointer");
-  const RcclEntry& e = rccl_entry();
-  DH_REQUIRE(e.allgather, "allgather_logits: %s", e.why ? e.why : "RCCL not found");
-  const int rc = e.allgather(send_dev, recv_dev, (size_t)n_per_rank * (size_t)n_cls, /* ncclFloat32 */ 7, comm, dh::as_stream(stream));
-  if (rc != 0) {
-    dh::set_error("allgather_logits: ncclAllGather failed: %s (%d)", e.errstr ? e.errstr(rc) : "?", rc);
+  RcclEntry e;
+  {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (!g_rccl.resolved) rccl_resolve(g_rccl);
+    e = g_rccl;
+  }
+  DH_REQUIRE(e.allgather, "allgather_logits: %s", e.why.empty() ? "RCCL not found" : e.why.c_str());
+  const ncclResult_t rc = e.allgather(send_dev, recv_dev, (size_t)n_per_rank * (size_t)n_cls, ncclFloat32, static_cast<ncclComm_t>(comm), dh::as_stream(stream));
+  if (rc != ncclSuccess) {
+    dh::set_error("allgather_logits: ncclAllGather failed: %s (%d)", e.errstr ? e.errstr(rc) : "?", (int)rc);
     return DH_EHIP;
   }
   return DH_OK;

@@ -10,6 +10,10 @@ Order matters on ROCm: the rank binds its GPU (`torch.cuda.set_device(LOCAL_RANK
 (`init_process_group("nccl", device_id=...)`: backend "nccl" IS RCCL) BEFORE any other GPU call, so no rank ever creates a
 context on cuda:0 by accident.  `DH_DIST_BACKEND=gloo` selects the CPU backend (tests, rehearsals on a one-GPU box together
 with `DH_SHARE_GPU=1`, which maps every rank to cuda:0).
+
+Timeouts: the group is created with an explicit collective timeout (`DH_DIST_TIMEOUT_S`, default 600 s, instead of the backend's
+own default of 10-30 minutes).  A rank whose peer is stuck then fails inside the collective -- RCCL's watchdog aborts the process,
+gloo raises -- and leaves through `finalize(owned, ok=False)`: non-zero exit, no barrier, no re-exec; the launcher tears the job down.
 """
 from __future__ import annotations
 
@@ -19,6 +23,20 @@ import os
 def env_world() -> tuple[int, int, int]:
     """(rank, world, local_rank) from the launcher's environment (1 process when absent)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def dist_timeout():
+    """Collective timeout of the process groups created here (DH_DIST_TIMEOUT_S seconds, default 600)."""
+    from datetime import timedelta
+
+    v = os.environ.get("DH_DIST_TIMEOUT_S", "600")
+    try:
+        sec = float(v)
+    except ValueError:
+        raise ValueError(f"DH_DIST_TIMEOUT_S={v!r}: expected seconds") from None
+    if not sec > 0:
+        raise ValueError(f"DH_DIST_TIMEOUT_S={v!r}: expected a positive number of seconds")
+    return timedelta(seconds=sec)
 
 
 def init_from_env():
@@ -38,9 +56,9 @@ def init_from_env():
         dev_index = 0 if os.environ.get("DH_SHARE_GPU") == "1" else local
         torch.cuda.set_device(dev_index)           # before anything else touches a GPU
     if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))   # RCCL over xGMI
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=dist_timeout())   # RCCL over xGMI
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, timeout=dist_timeout())
     return dist.get_rank(), dist.get_world_size(), dev_index, True
 
 

@@ -14,6 +14,11 @@ on the communication stream (`dh_grad_pack_bf16`, round to nearest even), all-re
 `finish()` unpacks the sums times 1 / world into the float32 arena (`dh_grad_unpack_bf16`): every rank holds the same bf16 sums, so the
 replicas stay identical; the averaged gradient carries a relative rounding error of <= 2^-8 per term, as in any bf16 gradient exchange.
 
+Overlap switch: `overlap=False` (or DH_DDP_OVERLAP=0) keeps the SAME buckets and the same arithmetic but starts them one after the other on
+the compute stream AFTER the backward pass (`finish()`), so nothing runs beside the persistent one-workgroup-per-CU convolution kernels: the
+fall-back -- and the A/B -- for a node where RCCL's kernels do not get CUs while those kernels hold the chip (bench.py reports `train_ddp` both
+ways).  Gradients are bit-equal in both modes (`tests/test_ddp.py`).
+
 The reference has no multi-GPU path (single process, train.py:59-301); semantics follow torch DDP: per-rank batch
 statistics, gradients averaged, replicas stay identical.
 """
@@ -31,6 +36,13 @@ def default_wire() -> str:
     if w not in ("f32", "bf16"):
         raise ValueError(f"DH_DDP_WIRE={w!r}: expected f32 or bf16")
     return w
+
+
+def default_overlap() -> bool:
+    v = os.environ.get("DH_DDP_OVERLAP", "1")
+    if v not in ("0", "1"):
+        raise ValueError(f"DH_DDP_OVERLAP={v!r}: expected 0 or 1")
+    return v == "1"
 
 
 def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
@@ -86,10 +98,12 @@ class BucketReducer:
     `on_bucket(bucket, offset, count)` may be called from a native callback while the producer is still enqueueing
     work; on CUDA tensors the collective is ordered behind everything enqueued so far on the current stream."""
 
-    def __init__(self, flat: torch.Tensor, group=None, wire: str | None = None):
+    def __init__(self, flat: torch.Tensor, group=None, wire: str | None = None, overlap: bool | None = None):
         import torch.distributed as dist
 
         self.flat, self.group = flat, group
+        self.overlap = default_overlap() if overlap is None else bool(overlap)
+        self.deferred = []   # overlap off: (offset, count) of the buckets reported so far; exchanged by finish()
         self.world = dist.get_world_size(group)
         self.works = []
         self.log = []   # (bucket, offset, count) in launch order
@@ -118,6 +132,10 @@ class BucketReducer:
     def on_bucket(self, bucket: int, offset: int, count: int) -> None:
         import torch.distributed as dist
 
+        self.log.append((int(bucket), int(offset), int(count)))
+        if not self.overlap:          # exchanged after the backward pass, in this order (finish)
+            self.deferred.append((int(offset), int(count)))
+            return
         bf16 = self.wire == "bf16"
         if self.cuda:
             ev = torch.cuda.Event()
@@ -129,13 +147,18 @@ class BucketReducer:
         else:
             piece = self._pack(offset, count) if bf16 else self.flat[offset:offset + count]
             self.works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self.log.append((int(bucket), int(offset), int(count)))
 
     def finish(self) -> torch.Tensor:
         """Wait for every bucket (the compute stream waits on the device; nothing blocks the host with nccl) and divide."""
+        import torch.distributed as dist
+
+        for offset, count in self.deferred:   # overlap off: the same buckets, in completion order, on the compute stream
+            piece = self._pack(offset, count) if self.wire == "bf16" else self.flat[offset:offset + count]
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+        self.deferred = []
         for w in self.works:
             w.wait()
-        if self.cuda:
+        if self.cuda and self.overlap:
             self.main.wait_stream(self.comm)
         covered = sum(c for _, _, c in self.log)
         if covered != self.flat.numel():

@@ -118,9 +118,13 @@ int dh_argmax_map(const float* canvas_dev, int64_t n_cells, int32_t n_cls, int64
  * float32[n_per_rank][n_cls] (ranges padded to a common length by the caller) and receives
  * float32[world][n_per_rank][n_cls] in rank order, after which each rank runs dh_accumulate_logits on the
  * whole list.  comm: the caller's RCCL communicator (ncclComm_t), created by the caller with the RCCL of
- * its process; RCCL is resolved from the process at the first call (librccl.so.1, or DH_RCCL_LIB) -- this
- * library does not link against it.  Asynchronous on `stream`.  The Python shims exchange through
- * torch.distributed instead (examples/predict_full_patched.py: exchange_logits). */
+ * its process.  The ncclAllGather that runs must belong to the SAME library instance that made `comm`: this
+ * library never links against or loads an RCCL of its own.  dh_set_rccl(handle) hands over the dlopen handle of
+ * the host's RCCL (exact; NULL = back to automatic); without it the first exchange takes DH_RCCL_LIB=<file>
+ * (must already be loaded), else a global ncclAllGather symbol, else an already-loaded librccl.so.1 / librccl.so;
+ * nothing loaded => DH_EINVAL.  Asynchronous on `stream`.  The Python shims exchange through torch.distributed
+ * instead (examples/predict_full_patched.py: exchange_logits). */
+int dh_set_rccl(void* dl_handle);
 int dh_allgather_logits(void* comm, const float* send_dev, float* recv_dev, int64_t n_per_rank,
                         int32_t n_cls, void* stream);
 

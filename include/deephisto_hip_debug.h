@@ -101,6 +101,9 @@ int dh_debug_bn_pool_f32(const float* z_dev, const float* gamma_dev, const float
 /* dh_debug_stamps: switch the 3x3-conv kernel to its cycle-stamped diagnostic variant and/or read
  * (and clear) its 8x8 table of summed phase cycles; out64_host may be NULL. */
 int dh_debug_stamps(int32_t enable, unsigned long long* out64_host);
+/* dh_debug_env_knobs: the table of every environment variable the library reads (csrc/env_knobs.h), one "NAME default lo hi read"
+ * line per knob, NUL-terminated, into buf_host[cap]; INTEGRATION.md lists the same table (tests/test_abi.py compares them). */
+int dh_debug_env_knobs(char* buf_host, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -262,6 +262,57 @@ int main(int argc, char** argv) {
       sweep_layer<2>(64, Hi, c, c, 1, false, 256, "r50-3x3");
       if (Hi > 7) sweep_layer<2>(64, Hi, c, c, 2, false, 256, "r50-3x3");
     }
+  // ---- refusal paths: the invariants the kernel relies on are refused by build_tables, not assumed by its callers
+  {
+    auto geom = [](int B, int Hi, int Wi, int cin, int cout) {
+      Geom p{};
+      p.B = B; p.Hi = Hi; p.Wi = Wi; p.Cin = cin; p.Cout = cout; p.Ho = Hi; p.Wo = Wi;
+      p.in_px_bytes = cin * 2; p.in_chunk_bytes = kChunkBytes; p.out_px = cout; p.out_mt = 32; p.out_cb = 64;
+      p.o_img = (int64_t)p.Ho * p.Wo * cout; p.o_row = p.Wo * p.out_px; p.o_px = p.out_px; p.o_base = 0;
+      p.out_pr = 16; p.res_mt = p.out_mt; p.res_pr = 16; p.r_row = p.o_row; p.r_px = p.o_px; p.r_cb = p.out_cb; p.r_base = 0;
+      return p;
+    };
+    auto refused = [](Geom p, const Cand& c, const char* expect) {
+      set_stride1_geometry(p, c, p.Ho, p.Wo);
+      p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
+      const int ncb = p.Cout / 64;
+      p.ntiles = ((p.B + p.IMGS - 1) / p.IMGS) * p.tiles_y * p.tiles_x * ncb;
+      const int grid = std::min(256, p.ntiles);
+      p.iters = (p.ntiles + grid - 1) / grid;
+      HostTables ht;
+      const char* why = build_tables<1, 2, 8, 2, 2, Geom>(p, ncb, 0, &ht);
+      REQUIRE(why && std::string(why).find(expect) != std::string::npos, "expected a refusal containing '%s', got '%s'", expect, why ? why : "(accepted)");
+      ++g_cases;
+    };
+    const Cand c512 = {16, 32, 1, 34, 0};
+    refused(geom(4, 64, 64, 32, 64), c512, "two whole channel stages");          // bf16, 32 channels: ONE 64-byte stage per tile
+    refused(geom(4, 64, 64, 80, 64), c512, "two whole channel stages");          // 160 bytes per pixel: not whole stages
+    refused(geom(1, 1040, 2048, 64, 64), c512, "too many distinct tile positions");   // 65 x 64 = 4 160 tile positions > 4 096 mask rows
+    {   // exactly 4 096 positions (mask rows 0 .. 4095: the descriptor word's bit 31 is used) is accepted and decodes
+      Geom p = geom(1, 1024, 2048, 64, 64);
+      set_stride1_geometry(p, c512, p.Ho, p.Wo);
+      p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
+      p.ntiles = p.tiles_y * p.tiles_x; p.iters = (p.ntiles + 255) / 256;
+      HostTables ht;
+      const char* why = build_tables<1, 2, 8, 2, 2, Geom>(p, 1, 0, &ht);
+      REQUIRE(!why && ht.mask_rows == 4096, "4 096 tile positions: %s, %d rows", why ? why : "accepted", ht.mask_rows);
+      unsigned top = 0;
+      for (const TileDesc& td : ht.tile) top = std::max(top, (unsigned)td.x >> 20);
+      REQUIRE(top == 4095, "highest mask row decodes as %u", top);
+      ++g_cases;
+    }
+    {   // a window past 64 KiB: 24 x 44 pixels x 64 bytes = 66 KiB (the 16-bit hoisted offsets would wrap)
+      Geom p = geom(4, 64, 64, 64, 64);
+      Cand big = {22, 32, 1, 44, 0};
+      set_stride1_geometry(p, big, p.Ho, p.Wo);
+      p.n_win_instr = (p.IMGS * p.HR * p.HP + 15) / 16;
+      p.ntiles = 4 * p.tiles_y * p.tiles_x; p.iters = 1;
+      HostTables ht;
+      const char* why = build_tables<1, 2, 8, 2, 2, Geom>(p, 1, 0, &ht);
+      REQUIRE(why && std::string(why).find("64 KiB") != std::string::npos, "oversized window: %s", why ? why : "(accepted)");
+      ++g_cases;
+    }
+  }
   printf("OK %ld\n", g_cases);
   return 0;
 }

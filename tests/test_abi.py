@@ -97,3 +97,62 @@ def test_tile_grid_property_against_the_pinned_oracle(built_lib):
         assert got.dtype == np.int32 and got.shape == want.shape and np.array_equal(got, want)
 
     check()
+
+
+def test_no_ablation_switch_in_shipped_library(built_lib):
+    """the timing-only ablations (DH_T2_ABL: whole kernel groups skipped, results garbage) and the gradient dump
+    (DH_TRAIN_DUMP) are compile-time macros of diagnostic builds; the shipped shared object does not know the names."""
+    from deephisto_amd import _lib
+    blob = _lib.LIB_PATH.read_bytes()
+    for name in (b"DH_T2_ABL", b"DH_TRAIN_DUMP", b"DH_ABL", b"SP_ABL"):
+        assert name not in blob, f"{name.decode()} is compiled into the shipped library"
+
+
+def _env_table(built_lib):
+    buf = C.create_string_buffer(1 << 16)
+    assert built_lib.dh_debug_env_knobs(buf, len(buf)) == 0
+    rows = [ln.split() for ln in buf.value.decode().splitlines()]
+    return {r[0]: (int(r[1]), int(r[2]), int(r[3]), r[4]) for r in rows}
+
+
+def test_env_knobs_are_one_table_and_documented(built_lib):
+    """Every DH_* name the shared object contains is a row of csrc/env_knobs.h (or DH_RCCL_LIB, a path), and INTEGRATION.md lists
+    every row with the same default and range."""
+    from deephisto_amd import _lib
+    table = _env_table(built_lib)
+    assert len(table) >= 10
+    in_binary = set(re.findall(rb"\x00(DH_[A-Z0-9_]{3,})(?=\x00)", _lib.LIB_PATH.read_bytes()))   # whole C strings (what a getenv would take)
+    names = {n.decode() for n in in_binary} - {"DH_RCCL_LIB", "DH_OK", "DH_EINVAL", "DH_ENOMEM", "DH_EHIP"}
+    assert names <= set(table), f"environment names outside env_knobs.h: {sorted(names - set(table))}"
+    doc = (REPO / "INTEGRATION.md").read_text()
+    for name, (default, lo, hi, read) in table.items():
+        m = re.search(rf"\| `{name}` \| (-?\d+) \| (-?\d+) \.\. (-?\d+) \| (\w+) \|", doc)
+        assert m, f"{name} is not documented in INTEGRATION.md"
+        assert (int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4)) == (default, lo, hi, read), name
+    assert "`DH_RCCL_LIB`" in doc
+
+
+def test_unrecognised_env_value_is_refused_by_name(built_lib, monkeypatch):
+    """A mistyped switch is not atoi'd: the create entry points fail before any GPU call and dh_last_error() names the variable."""
+    h = C.c_void_p()
+    for name, bad in (("DH_T2_FOLD", "yes"), ("DH_CONV_S2_WIDE", "2"), ("DH_G2_NS3_K", "12x"), ("DH_T2_SIDE", "")):
+        monkeypatch.setenv(name, bad)
+        assert built_lib.dh_train2_create(C.byref(h), b"resnet50", 5) == -22
+        assert name.encode() in built_lib.dh_last_error()
+        assert built_lib.dh_resnet18_create(C.byref(h), 5, 1) == -22
+        assert name.encode() in built_lib.dh_last_error()
+        monkeypatch.delenv(name)
+
+
+def test_rccl_entry_never_loads_a_library_of_its_own(built_lib, monkeypatch):
+    """dh_allgather_logits only ever calls into an RCCL that is already in the process: a handle without ncclAllGather is
+    refused, and so is an exchange in a process that has loaded no RCCL at all."""
+    libc = C.CDLL("libc.so.6")
+    assert built_lib.dh_set_rccl(C.c_void_p(libc._handle)) == -22 and b"ncclAllGather" in built_lib.dh_last_error()
+    assert built_lib.dh_set_rccl(None) == 0
+    monkeypatch.setenv("DH_RCCL_LIB", "/nonexistent/librccl.so.1")
+    dummy = (C.c_float * 8)()
+    comm = C.c_void_p(1)
+    assert built_lib.dh_allgather_logits(comm, dummy, dummy, 1, 5, None) == -22
+    assert b"not loaded in this process" in built_lib.dh_last_error()
+    assert built_lib.dh_set_rccl(None) == 0

@@ -122,6 +122,14 @@ def _bucket_worker(rank, world, port, q):
     for b, (off, cnt) in enumerate(ranges):
         red.on_bucket(b, off, cnt)
     out = red.finish()
+    # overlap off (DH_DDP_OVERLAP=0 / overlap=False): same buckets, exchanged one after the other by finish(): same bits
+    flat2 = torch.randn(10_000, generator=torch.Generator().manual_seed(7 + rank))
+    late = BucketReducer(flat2, None, overlap=False)
+    for b, (off, cnt) in enumerate(ranges):
+        late.on_bucket(b, off, cnt)
+    assert not late.works and len(late.deferred) == 3          # nothing started before finish()
+    out_late = late.finish()
+    assert torch.equal(out_late, out) and late.log == red.log
     ok_cover = True
     try:
         bad = BucketReducer(torch.zeros(10), None)
@@ -258,7 +266,15 @@ def _gpu_bf16_worker(rank, world, port, q):
     got = m2.flat_gradients(dev).clone().cpu()     # the arena still holds the averaged gradients after Adam
     log = m2._engine.overlap_log
     sd = m2.state_dict()
-    q.put((rank, float(loss), bool(torch.equal(got, want)), log, sd["fc.weight"].cpu().numpy(), sd["conv1.weight"].cpu().numpy()))
+    # DH_DDP_OVERLAP=0: the same buckets exchanged after the backward pass -- the fall-back must give the same bits
+    os.environ["DH_DDP_OVERLAP"] = "0"
+    m3 = get_model(5, arch="resnet50")
+    m3.load_state_dict(ref.state_dict())
+    m3.to(dev).train()
+    loss3, _ = m3.train_step(x, y, lr=1e-4, bucket_bytes=25 * 1024 * 1024)
+    late_equal = bool(torch.equal(m3.flat_gradients(dev).cpu(), got)) and float(loss3) == float(loss) and m3._engine.overlap_log == log
+    del os.environ["DH_DDP_OVERLAP"]
+    q.put((rank, float(loss), bool(torch.equal(got, want)), log, sd["fc.weight"].cpu().numpy(), sd["conv1.weight"].cpu().numpy(), late_equal))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -278,6 +294,7 @@ def test_ddp_resnet50_bf16_bucketed_overlap(built_lib):
     for r in range(world):
         assert got[r][2], "bucketed gradients differ from the single all-reduce"
         assert [b for b, _, _ in got[r][3]] == [0, 1, 2, 3]
+        assert got[r][6], "DH_DDP_OVERLAP=0 (exchange after the backward pass) changed the gradients"
     assert np.array_equal(got[0][4], got[1][4]) and np.array_equal(got[0][5], got[1][5])
 
 

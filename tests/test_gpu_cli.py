@@ -132,4 +132,26 @@ def test_bench_self_launch_two_ranks_share_gpu(built_lib, tmp_path):
     assert "error" not in dd, dd
     assert dd["config"]["ranks"] == 2 and "allreduce_exposed_ms" in dd and "local_step_ms" in dd
     assert dd["wire_bf16"]["ms_per_step"] > 0
+    assert dd["overlap_off"]["ms_per_step"] > 0          # DH_DDP_OVERLAP=0: the same buckets after the backward pass (round 5)
     assert out["cpu_baseline"]["value"] > 0 and out["roofline"]["frac"] >= 0
+    # round 5: the line says what the process group saw -- every rank's device and tile range, gathered over the group
+    rk = out["ranks"]
+    assert [r["rank"] for r in rk] == [0, 1] and len({r["pid"] for r in rk}) == 2
+    assert (rk[0]["tile_lo"], rk[0]["tile_hi"], rk[1]["tile_lo"], rk[1]["tile_hi"]) == (0, 128, 128, 256)
+    assert all(r["device"] == 0 for r in rk) and out["distinct_devices"] == 1 and "gloo" in out["backend"]
+
+
+def test_bench_failing_ddp_leg_is_agreed_through_the_store(built_lib, tmp_path):
+    """a failure inside the train_ddp leg must not meet its peers' collectives in a barrier.  Here the leg fails on
+    every rank (an invalid wire format): the ranks agree through the rendezvous store, the headline line still appears with the
+    error inside `train_ddp`, and the job ends cleanly."""
+    import json
+    env = dict(os.environ, DH_BENCH_SHARE_GPU="1", DH_BENCH_FAIL_DDP="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--slide", "4096", "--steps", "1", "--warmup", "1",
+           "--train-steps", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert out["value"] > 0 and "DH_BENCH_FAIL_DDP" in out["train_ddp"]["error"]

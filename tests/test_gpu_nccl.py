@@ -101,6 +101,13 @@ def _worker_cabi(q):
     send = torch.randn(4802, 5, device=dev)
     recv = torch.zeros_like(send)
     st = torch.cuda.current_stream().cuda_stream
+    # a library named in DH_RCCL_LIB that is not loaded in the process is refused (never a second RCCL beside the communicator's own)
+    os.environ["DH_RCCL_LIB"] = "/nonexistent/librccl.so.1"
+    out["bad_env"] = lib().dh_allgather_logits(comm, send.data_ptr(), recv.data_ptr(), 4802, 5, st)
+    out["bad_env_msg"] = lib().dh_last_error().decode()
+    del os.environ["DH_RCCL_LIB"]
+    # the exact answer: the dlopen handle of the library that made `comm`
+    out["set"] = lib().dh_set_rccl(C.c_void_p(rccl._handle))
     out["rc"] = lib().dh_allgather_logits(comm, send.data_ptr(), recv.data_ptr(), 4802, 5, st)
     torch.cuda.synchronize()
     out["equal"] = bool(torch.equal(send, recv))          # one rank: the gathered list is the rank's own
@@ -120,5 +127,6 @@ def test_c_abi_allgather_on_one_rank(built_lib):
     p.join(timeout=120)
     assert p.exitcode == 0
     assert out["uid"] == 0 and out["init"] == 0, out
-    assert out["rc"] == 0 and out["equal"], out
+    assert out["bad_env"] == -22 and "not loaded in this process" in out["bad_env_msg"], out
+    assert out["set"] == 0 and out["rc"] == 0 and out["equal"], out
     assert out["null_comm"] == -22 and out["null_ptr"] == -22 and out["empty"] == 0, out

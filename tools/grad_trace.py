@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Compare the intermediate gradients dumped by DH_TRAIN_DUMP with the CPU oracle's (backward hooks). Tooling only.
+Needs a DIAGNOSTIC build of the library (tools/build_variant.sh dump -DDH_TRAIN_DUMP_BUILD=1, copied over libdeephisto_hip.so):
+the shipped library compiles the dump to nothing.
 usage: grad_trace.py B P"""
 import os
 import sys
