@@ -4,8 +4,20 @@
 // tests/host/conv3_tables_sweep.cpp compiles it with `g++ -fsanitize=address,undefined` and sweeps the shapes the engines use,
 // asserting that every offset lies inside its tensor and fits its integer type (tests/test_conv_tables_host.py, CPU only).
 //
-// `P` is any struct with the geometry fields of Conv3Params (TH, TW, IMGS, HR, HC, HP, HPH, Hi, Wi, Cin, B, tiles_y, tiles_x,
+// `P` is any struct with the geometry fields of Conv3Params (TH, TW, IMGS, HR, HC, HP, HPH, WTAIL, FIT, IP, Hi, Wi, Cin, B, tiles_y, tiles_x,
 // n_win_instr, in_px_bytes, Ho, Wo, Cout, out_px, out_cb, o_img, o_row, o_px, o_base, r_row, r_px, r_cb, r_base, ntiles, iters).
+//
+// Round 5: "fit" tile shapes for maps whose side is 7 * 2^k (every layer of a 224-pixel patch: 56 / 28 / 14 / 7).  Power-of-two tiles
+// fill 49 / 64 of their slots there.  A fit tile takes whole 7 x 7 images (ten per 512-slot tile, 490 slots) or half-images of 7 x 14
+// (five per tile, 490 slots); the slot count need not be filled (FIT: IMGS * TH * TW <= slots, the rest are masked lanes), and where a
+// tile covers the map's full width / height the zero halo column / row is SHARED between neighbouring rows / images (HP = TW + 1,
+// HR = TH + 1): the pixel right of a row's last pixel is the (always zero) left halo of the next row, so the staged window is
+// IMGS * HR * HP + WTAIL pixels instead of IMGS * (TH + 2) * (TW + 2) -- that is what makes ten 7 x 7 images (649 pixels) and five
+// 7 x 14 half-images (676) fit the 43 KiB a window may take beside two 36 KiB weight slabs.  Lanes are dealt to pixels by the
+// residue of their window index mod 16 (deal_fit_pixels), the condition under which the swizzled window image is read conflict-free;
+// the image segments of a fit window are IP pixels apart (IP >= HR * HP: the gap pixels are never staged, i.e. zero), chosen so that
+// the residues come out even: at pitch 8 the 7-pixel rows of ten images at IP = 64 never produce residues 7 and 15 (21 of 32 service
+// groups would read with 2-way conflicts), at IP = 67 every residue occurs at most 32 times: conflict-free.
 #pragma once
 #include <algorithm>
 #include <array>
@@ -32,9 +44,28 @@ constexpr int max_window_pieces() { return (STRIDE == 2) ? (WAVES == 8 ? 5 : 10)
 
 // Tile shapes of the stride-1 kernel from the largest down: {TH, TW, IMGS, HP, variant}; variant 0: NT=2 MT=2 (512 pixels),
 // 1: NT=1 MT=2 (256), 2: NT=1 MT=1 (128).  The first candidate that gives the launch `min_tiles` tiles wins, else the smallest.
-struct Cand { int th, tw, imgs, hp, variant; };
-inline int stride1_candidates(int Ho, int Wo, Cand (&c)[4]) {
+// hr = 0: TH + 2 window rows per image segment (own halo rows); wtail: window pixels behind the last segment; fit: see the header
+struct Cand { int th, tw, imgs, hp, variant, hr = 0, wtail = 0, fit = 0, ip = 0; };   // ip = 0: segments HR * HP pixels apart
+constexpr int kMaxCands = 6;
+inline int stride1_candidates(int Ho, int Wo, Cand (&c)[kMaxCands], bool fit = true) {
   int nc = 0;
+  if (fit && Ho == 7 && Wo == 7) {
+    // whole 7 x 7 images, halo row and column shared (pitch 8, 8 rows per image; tail = one halo row + 1): 10 images = 490 / 512 slots,
+    // 5 images = 245 / 256
+    // segments 67 pixels apart (see the header); window = (IMGS - 1) * 67 + 8 * 8 + 9 pixels = IMGS * 64 + wtail
+    c[nc++] = {7, 7, 10, 8, 0, 8, 9 * 3 + 9, 1, 67};
+    c[nc++] = {7, 7, 5, 8, 1, 8, 4 * 3 + 9, 1, 67};
+    c[nc++] = {8, 8, 2, 12, 2};
+    return nc;
+  }
+  if (fit && Ho == 14 && Wo == 14) {
+    // half-images of 7 rows x 14 columns from five images: 490 / 512 slots, 2 tiles per 5 images; the halo COLUMN is shared (full
+    // width: pitch 15), the halo rows are real rows of the image (HR = 9); tail = the last row's right halo
+    c[nc++] = {7, 14, 5, 15, 0, 9, 1, 1};
+    c[nc++] = {16, 16, 1, 18, 1};
+    c[nc++] = {8, 8, 2, 12, 2};
+    return nc;
+  }
   if (Wo > 16) {
     // 16x32 or 8x64 output pixels, whichever wastes fewer tile slots (56x56: 77 % vs 88 % useful)
     const int slots_a = ((Ho + 15) / 16) * ((Wo + 31) / 32), slots_b = ((Ho + 7) / 8) * ((Wo + 63) / 64);
@@ -54,9 +85,9 @@ inline int stride1_candidates(int Ho, int Wo, Cand (&c)[4]) {
 inline int tiles_of(const Cand& c, int B, int Ho, int Wo, int cout) {
   return Ho > 0 && Wo > 0 ? ((B + c.imgs - 1) / c.imgs) * ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw) * (cout / 64) : 0;
 }
-inline Cand pick_stride1(int B, int Ho, int Wo, int cout, int min_tiles) {
-  Cand c[4];
-  const int nc = stride1_candidates(Ho, Wo, c);
+inline Cand pick_stride1(int B, int Ho, int Wo, int cout, int min_tiles, bool fit = true) {
+  Cand c[kMaxCands];
+  const int nc = stride1_candidates(Ho, Wo, c, fit);
   for (int i = 0; i < nc; ++i)
     if (tiles_of(c[i], B, Ho, Wo, cout) >= min_tiles) return c[i];
   return c[nc - 1];
@@ -66,11 +97,12 @@ template <class P> inline void set_stride2_geometry(P& p, int Ho, int Wo) {
   if (Wo > 8) { p.TH = 8; p.TW = 16; p.IMGS = 1; }
   else { p.TH = 8; p.TW = 8; p.IMGS = 2; }
   p.HR = 2 * p.TH + 1; p.HC = 2 * p.TW + 1; p.HPH = p.TW + 1; p.HP = 2 * p.HPH;
+  p.WTAIL = 0; p.FIT = 0; p.IP = p.HR * p.HP;
   p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
 }
 template <class P> inline void set_stride1_geometry(P& p, const Cand& c, int Ho, int Wo) {
   p.TH = c.th; p.TW = c.tw; p.IMGS = c.imgs; p.HP = c.hp; p.HPH = 0;
-  p.HR = p.TH + 2; p.HC = p.TW + 2;
+  p.HR = c.hr ? c.hr : p.TH + 2; p.HC = p.TW + 2; p.WTAIL = c.wtail; p.FIT = c.fit; p.IP = c.ip ? c.ip : p.HR * p.HP;
   p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
 }
 
@@ -81,14 +113,57 @@ template <class P> inline bool set_stride2_wide_geometry(P& p, int Ho, int Wo) {
   else if (Wo > 8) { p.TH = 16; p.TW = 16; }
   else if (Wo > 4) { p.TH = 8; p.TW = 8; p.IMGS = 4; }   // four images per tile
   else return false;
+  p.WTAIL = 0; p.FIT = 0;
   p.HR = 2 * p.TH + 1; p.HC = 2 * p.TW + 1; p.HPH = p.TW + 1; p.HP = 2 * p.HPH;
   // 8 x 8 maps: the odd-column plane has one column fewer than the even one; without the dead column the four windows are 4 x 17 x 17 pixels =
   // 37 KB and 2 x (40 + 37) KB + tables fit 160 KB (with it: 162 KB).  The price: a row pitch of 34 pixels puts two of a 16-lane group's
   // pixels on one bank group (2-way conflicts on the window fragment reads) -- measured worth it: layer 4's stride-2 conv on the wide kernel
   // is +2.0 % on the whole slide (209.0 k -> 213.2 k patches/s, three passes, one box)
   if (p.TW == 8) p.HP = 2 * p.HPH - 1;
+  p.IP = p.HR * p.HP;
   p.tiles_y = (Ho + p.TH - 1) / p.TH; p.tiles_x = (Wo + p.TW - 1) / p.TW;
   return true;
+}
+
+// FIT tiles: which pixel of the tile (q = (img * TH + ty) * TW + tx, or -1) each slot of the workgroup's n-tiles computes.  A slot is
+// (n-tile t, lane position ll < 32); a ds_read_b128 of a half-wave is served in two groups of 16 lanes, A = {0-3, 12-15, 20-27} and
+// B = {4-11, 16-19, 28-31}, and the swizzled window image is read without bank conflicts when the 16 pixels of a group have 16 different
+// window indices mod 16 (the nine taps shift all of them alike).  Phase 1 deals every group at most one pixel per residue, richest
+// residues first; phase 2 puts what is left (residues that occur more often than there are groups: 7-pixel rows at pitch 8 never produce
+// residues 7 and 15) into the free lanes group by group, so that the unavoidable 2-way conflicts sit in as few groups as possible.
+inline std::vector<int> deal_fit_pixels(int imgs, int th, int tw, int ip, int hp, int ntile32) {
+  static const int ga[16] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
+  static const int gb[16] = {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
+  std::vector<int> slot((size_t)ntile32 * 32, -1);
+  std::vector<std::vector<int>> bucket(16);
+  for (int q = imgs * th * tw - 1; q >= 0; --q) {   // (reversed: pop_back hands them out in increasing order)
+    const int img = q / (th * tw), ty = (q % (th * tw)) / tw, tx = q % tw;
+    bucket[(img * ip + ty * hp + tx) & 15].push_back(q);
+  }
+  const int ngroups = ntile32 * 2;
+  std::vector<std::array<bool, 16>> used((size_t)ngroups);
+  std::vector<int> fill((size_t)ngroups, 0);
+  auto lane_of = [&](int g, int k) { return (g >> 1) * 32 + ((g & 1) ? gb[k] : ga[k]); };
+  for (int g = 0; g < ngroups; ++g) {
+    used[g].fill(false);
+    int order[16];
+    for (int r = 0; r < 16; ++r) order[r] = r;
+    std::stable_sort(order, order + 16, [&](int a, int b) { return bucket[a].size() > bucket[b].size(); });
+    for (int i = 0; i < 16; ++i) {
+      const int r = order[i];
+      if (bucket[r].empty()) continue;
+      slot[lane_of(g, fill[g]++)] = bucket[r].back();
+      bucket[r].pop_back();
+      used[g][r] = true;
+    }
+  }
+  for (int g = 0; g < ngroups; ++g)      // phase 2: leftovers, concentrated
+    for (int r = 0; r < 16 && fill[g] < 16; ++r)
+      if (!bucket[r].empty()) { slot[lane_of(g, fill[g]++)] = bucket[r].back(); bucket[r].pop_back(); }
+  for (int g = 0; g < ngroups; ++g)      // (a residue richer than two per group: keep filling)
+    for (int r = 0; r < 16; ++r)
+      while (!bucket[r].empty() && fill[g] < 16) { slot[lane_of(g, fill[g]++)] = bucket[r].back(); bucket[r].pop_back(); }
+  return slot;
 }
 
 // Returns nullptr, or the reason the shape cannot be scheduled.  `grid_override` > 0: the launch's share of a merged launch.
@@ -107,8 +182,25 @@ const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out
   //  * a descriptor word holds the cout block in bits 0-15, `valid` in bit 16 and the mask row in bits 20-31.
   constexpr int STAGE_PX_BYTES = HALF ? kChunkBytes / 2 : kChunkBytes;
   if ((int64_t)p.Cin * ESZ < 2 * STAGE_PX_BYTES || ((int64_t)p.Cin * ESZ) % STAGE_PX_BYTES) return "conv3x3: needs at least two whole channel stages per tile";
-  if ((int64_t)p.IMGS * p.HR * p.HP * STAGE_PX_BYTES > 65536) return "conv3x3: staged window larger than 64 KiB (16-bit fragment offsets)";
-  if ((int64_t)p.n_win_instr * 1024 < (int64_t)p.IMGS * p.HR * p.HP * STAGE_PX_BYTES) return "conv3x3: the DMA plan does not cover the staged window";
+  const int64_t win_px = (int64_t)p.IMGS * p.HR * p.HP + p.WTAIL;
+  const int IP = p.IP ? p.IP : p.HR * p.HP;   // pixels between image segments (0 = unset: dense)
+  if (win_px * STAGE_PX_BYTES > 65536) return "conv3x3: staged window larger than 64 KiB (16-bit fragment offsets)";
+  if ((int64_t)p.n_win_instr * 1024 < win_px * STAGE_PX_BYTES) return "conv3x3: the DMA plan does not cover the staged window";
+  constexpr int NTILE32 = (HALF ? WAVES / 2 : WAVES * MT / 2) * NT;   // 32-pixel n-tiles of a workgroup
+  if (p.FIT) {
+    if (STRIDE != 1 || HALF) return "conv3x3: fit tiles are stride-1 tiles";
+    if (p.IMGS * p.TH * p.TW > NTILE32 * 32) return "conv3x3: fit tile larger than the workgroup's slots";
+    // shared halos are zero only where they lie outside the image: a shared column needs full-width tiles, a shared row whole images
+    if (p.HP < p.TW + 1 || p.HR < p.TH + 1) return "conv3x3: fit tile pitch too small";
+    if (p.HP == p.TW + 1 && (p.TW != p.Wo || p.tiles_x != 1)) return "conv3x3: a shared halo column needs tiles of the map's full width";
+    if (p.HR == p.TH + 1 && (p.TH != p.Ho || p.tiles_y != 1)) return "conv3x3: a shared halo row needs tiles of the map's full height";
+    if (IP < p.HR * p.HP) return "conv3x3: fit tile segments overlap";
+    // the last tap of the last pixel reads window index (IMGS - 1) IP + (TH + 1) HP + TW + 1
+    if ((int64_t)(p.IMGS - 1) * IP + (int64_t)(p.TH + 1) * p.HP + p.TW + 1 >= win_px) return "conv3x3: fit tile window tail too short";
+  } else if (p.IMGS * p.TH * p.TW != NTILE32 * 32 || p.WTAIL != 0 || p.HR != STRIDE * p.TH + (STRIDE == 2 ? 1 : 2) || IP != p.HR * p.HP) {
+    return "conv3x3: tile / pixel mismatch";
+  }
+  const std::vector<int> fit_slot = p.FIT ? deal_fit_pixels(p.IMGS, p.TH, p.TW, IP, p.HP, NTILE32) : std::vector<int>();
   if (ncb < 1 || ncb > 65535) return "conv3x3: cout block count does not fit the descriptor word";
   std::vector<int>& lane = out->lane;
   lane.assign((size_t)threads * stride, 0);
@@ -132,14 +224,21 @@ const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out
       return (in_a ? 0 : 8) + (rank < 8 ? rank : rank + 8);   // TW == 8: A -> rows 0, 2; B -> rows 1, 3
     };
     for (int nt = 0; nt < NT; ++nt) {
-      const int pidx = ((MT == 2 && !HALF ? wave : wave >> 1) * NT + nt) * 32 + lane_pos(l & 31);   // MT == 1 / HALF: wave pairs share pixels
+      const int tile32 = (MT == 2 && !HALF ? wave : wave >> 1) * NT + nt;   // MT == 1 / HALF: wave pairs share pixels
+      int pidx = tile32 * 32 + lane_pos(l & 31);
+      if (p.FIT) pidx = fit_slot[(size_t)tile32 * 32 + (l & 31)];
+      if (pidx < 0) {   // FIT: a slot without a pixel -- never valid (image index IMGS), addresses harmless
+        pix[(size_t)tid * NT + nt] = {0, 0, p.IMGS};
+        row[nt] = 0; row[NT + nt] = 0; row[2 * NT + nt] = 0;
+        continue;
+      }
       const int img = pidx / (p.TH * p.TW), rem = pidx % (p.TH * p.TW);
       const int ty = rem / p.TW, tx = rem % p.TW;
       pix[(size_t)tid * NT + nt] = {ty, tx, img};
       const int64_t orel = (int64_t)img * p.o_img + (int64_t)ty * p.o_row + (int64_t)tx * p.o_px;   // relative to the tile's origin
       if (orel < 0 || orel > INT32_MAX) return "conv3x3: per-lane output offset does not fit 31 bits";
       row[nt] = (int)orel;
-      row[NT + nt] = (img * p.HR + ty * STRIDE) * p.HP + tx;
+      row[NT + nt] = img * IP + ty * STRIDE * p.HP + tx;
       const int64_t rrel = (int64_t)img * p.o_img + (int64_t)ty * p.r_row + (int64_t)tx * p.r_px;   // the residual's own layout
       if (rrel < 0 || rrel > INT32_MAX) return "conv3x3: per-lane residual offset does not fit 31 bits";
       row[2 * NT + nt] = (int)rrel;
@@ -149,11 +248,11 @@ const char* build_tables(const P& p, int ncb, int grid_override, HostTables* out
     for (int j = 0; j < MAXJ; ++j) {
       const int i = wave + WAVES * j;
       const int px = HALF ? i * 32 + (l >> 1) : i * 16 + (l >> 2);
-      const int img = px / (p.HR * p.HP), r = px % (p.HR * p.HP);
+      const int img = px / IP, r = px % IP;   // (r >= HR * HP: a gap pixel between the segments of a fit window -- never staged)
       const int hy = r / p.HP, c = r % p.HP;
       int hx = c;
       if (STRIDE == 2) hx = 2 * (c % p.HPH) + c / p.HPH;
-      const bool live = i < p.n_win_instr && img < p.IMGS && hx < p.HC;
+      const bool live = i < p.n_win_instr && img < p.IMGS && hy < p.HR && hx < p.HC;
       const int g = HALF ? (l & 1) ^ ((px >> 3) & 1) : (l & 3) ^ ((px >> 2) & 3);
       const int64_t roff = (int64_t)img * img_in_bytes + ((int64_t)(hy - 1) * p.Wi + hx - 1) * p.in_px_bytes + g * 16;
       if (live && (roff < INT32_MIN || roff > INT32_MAX)) return "conv3x3: per-lane window offset does not fit 32 bits";

@@ -744,7 +744,7 @@ constexpr size_t CONV3_TABLE_CAP = 256;
 template <int STRIDE, int NT, int WAVES, int ESZ, int MT, bool HALF = false>
 int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out, int grid_override = 0) {
   const std::vector<int> key = {current_device(), STRIDE, NT, WAVES, MT + (HALF ? 100 : 0), ESZ, p.TH, p.TW, p.IMGS, p.HR, p.HC, p.HP, p.HPH, p.Hi, p.Wi,
-                                p.Cin, p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.in_px_bytes, p.Ho, p.Wo, p.Cout, p.out_px,
+                                p.Cin, p.B, p.tiles_y, p.tiles_x, ncb, p.n_win_instr, p.WTAIL, p.FIT, p.IP, p.in_px_bytes, p.Ho, p.Wo, p.Cout, p.out_px,
                                 p.out_cb, (int)(p.o_img & 0x7FFFFFFF), (int)(p.o_img >> 31), p.o_row, p.o_px, p.o_base, grid_override, p.iters,
                                 p.r_row, p.r_px, p.r_cb, p.r_base};
   std::lock_guard<std::mutex> lk(g_host_mu);
@@ -776,17 +776,19 @@ int conv3_tables(const Conv3Params& p, int ncb, int groups_img, Conv3Tables* out
 template <typename T, int STRIDE, int NT, int WAVES, bool DS = false, int MT = 2, bool WRES = false, int CLS = -1, bool HALF = false>
 int launch_conv3x3_cfg(Conv3Params& p, const ConvLayer& L, hipStream_t st) {
   constexpr int STAGE_PX_BYTES = HALF ? CHUNK_BYTES / 2 : CHUNK_BYTES, CO_BLK = HALF ? 128 : 64;
-  const int win_bytes = p.IMGS * p.HR * p.HP * STAGE_PX_BYTES;
+  const int win_px = p.IMGS * p.HR * p.HP + p.WTAIL;
+  const int win_bytes = win_px * STAGE_PX_BYTES;
   const size_t wslab = (size_t)(9 + (DS ? 1 : 0)) * SLAB_TAP, win_alloc = (win_bytes + 1023) & ~1023;
   const size_t nchunks = (size_t)L.cin * sizeof(T) / STAGE_PX_BYTES;
   // 2-deep ring of [weight slab | window] (WRES: all weight slabs once + ring of windows) + [2][scale|shift(|ds scale|ds shift)]
   const size_t lds = (WRES ? nchunks * wslab + 2 * win_alloc : 2 * (wslab + win_alloc)) + (HALF ? 4096 : DS ? 2048 : 1024);
 
   constexpr int MAXJ = (STRIDE == 2) ? (WAVES == 8 ? 5 : 10) : (NT == 2 ? 6 : 4);
-  p.n_win_instr = HALF ? (p.IMGS * p.HR * p.HP + 31) / 32 : (p.IMGS * p.HR * p.HP + 15) / 16;
+  p.n_win_instr = HALF ? (win_px + 31) / 32 : (win_px + 15) / 16;
   DH_REQUIRE(p.n_win_instr <= MAXJ * WAVES, "conv3x3: staging window too large for the DMA plan");
   DH_REQUIRE(lds <= 160 * 1024, "conv3x3: LDS budget exceeded (%zu B)", lds);
-  DH_REQUIRE(p.IMGS * p.TH * p.TW == (HALF ? WAVES / 2 : WAVES * MT / 2) * NT * 32, "conv3x3: tile/pixel mismatch");
+  DH_REQUIRE(p.FIT ? p.IMGS * p.TH * p.TW <= (WAVES * MT / 2) * NT * 32 && STRIDE == 1 && !HALF
+                   : p.IMGS * p.TH * p.TW == (HALF ? WAVES / 2 : WAVES * MT / 2) * NT * 32, "conv3x3: tile/pixel mismatch");
   DH_REQUIRE(L.cin * (int)sizeof(T) >= 2 * CHUNK_BYTES, "conv3x3: needs at least two channel chunks");
   const int groups = ((p.B + p.IMGS - 1) / p.IMGS) * p.tiles_y * p.tiles_x;
   p.ntiles = groups * (L.cout / CO_BLK);
@@ -886,12 +888,14 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     // candidates from the largest tile down; the first that gives every CU a tile wins, else the smallest (round 3: a launch
     // with few pixels -- a parity class of a stride-2 data gradient at batch 64 -- used to run 512-pixel tiles on half the chip)
     constexpr int min_tiles = 256;
-    const dh_conv3::Cand cd = dh_conv3::pick_stride1(B, Ho, Wo, L.cout, min_tiles);   // conv3_tables_host.h
+    // DH_CONV_FIT=0: the round-4 candidate list (power-of-two tiles only) for A/B; default: fit tiles for 7 x 7 and 14 x 14 maps too
+    static const bool fit_tiles = dh::env_int("DH_CONV_FIT") != 0;
+    const dh_conv3::Cand cd = dh_conv3::pick_stride1(B, Ho, Wo, L.cout, min_tiles, fit_tiles && CLS < 0);   // conv3_tables_host.h
     dh_conv3::set_stride1_geometry(p, cd, Ho, Wo);
     variant = cd.variant;
     if ((rc = maybe_sample(variant == 0 && CLS < 0))) return rc;
     // weights resident in LDS when the layer has one cout block and its slabs fit beside the window ring (bf16 64 -> 64)
-    const size_t wres_lds = (size_t)L.cin * sizeof(T) / CHUNK_BYTES * 9 * SLAB_TAP + 2 * (((size_t)p.IMGS * p.HR * p.HP * CHUNK_BYTES + 1023) & ~(size_t)1023) + 1024;
+    const size_t wres_lds = (size_t)L.cin * sizeof(T) / CHUNK_BYTES * 9 * SLAB_TAP + 2 * (((size_t)(p.IMGS * p.HR * p.HP + p.WTAIL) * CHUNK_BYTES + 1023) & ~(size_t)1023) + 1024;
     if constexpr (CLS >= 0)
       rc = variant == 0 ? launch_conv3x3_cfg<T, 1, 2, 8, false, 2, false, CLS>(p, L, st)
          : variant == 1 ? launch_conv3x3_cfg<T, 1, 1, 8, false, 2, false, CLS>(p, L, st)

@@ -25,7 +25,7 @@ struct Geom {   // the geometry fields of Conv3Params
   int in_px_bytes, in_chunk_bytes, out_px, out_cb, out_mt;
   int64_t o_img; int o_row, o_px, o_base;
   int out_pr, res_mt, res_pr, r_row, r_px, r_cb, r_base;   // output half-tile stride; the residual's own layout
-  int TH, TW, IMGS, tiles_y, tiles_x, HR, HC, HP, HPH, n_win_instr, ntiles, iters;
+  int TH, TW, IMGS, tiles_y, tiles_x, HR, HC, HP, HPH, WTAIL, FIT, IP, n_win_instr, ntiles, iters;
 };
 
 static long g_cases = 0;
@@ -38,9 +38,15 @@ static void check_case(Geom p, int in_layout, int out_layout, int grid_override,
   constexpr int CO_BLK = HALF ? 128 : 64, PXB = HALF ? 32 : 64;   // couts per workgroup; bytes of a pixel per stage
   const bool blocked = in_layout != 0;
   const int ncb = p.Cout / CO_BLK;
-  p.n_win_instr = HALF ? (p.IMGS * p.HR * p.HP + 31) / 32 : (p.IMGS * p.HR * p.HP + 15) / 16;
+  const int win_px = p.IMGS * p.HR * p.HP + p.WTAIL;
+  if (!p.IP) p.IP = p.HR * p.HP;
+  p.n_win_instr = HALF ? (win_px + 31) / 32 : (win_px + 15) / 16;
   REQUIRE(p.n_win_instr <= MAXJ * WAVES, "%s: window too large for the DMA plan", what);
-  REQUIRE(p.IMGS * p.TH * p.TW == (HALF ? WAVES / 2 : WAVES * MT / 2) * NT * 32, "%s: tile/pixel mismatch", what);
+  const int slots = (HALF ? WAVES / 2 : WAVES * MT / 2) * NT * 32;
+  REQUIRE(p.FIT ? p.IMGS * p.TH * p.TW <= slots : p.IMGS * p.TH * p.TW == slots, "%s: tile/pixel mismatch", what);
+  // the LDS budget of the launch (launch_conv3x3_cfg): two ring slots of [36 KiB weight slab (+ 4 KiB downsample slab) | window] + tables
+  REQUIRE(2 * ((size_t)(9 + (STRIDE == 2 && !HALF ? 1 : 0)) * 4096 + (((size_t)win_px * PXB + 1023) & ~(size_t)1023)) + (HALF ? 4096 : 2048) <= 160 * 1024 || HALF,
+          "%s: window of %d pixels does not fit the LDS ring", what, win_px);
   const int groups = ((p.B + p.IMGS - 1) / p.IMGS) * p.tiles_y * p.tiles_x;
   p.ntiles = groups * ncb;
   const int grid = grid_override > 0 ? grid_override : std::min(256, p.ntiles);
@@ -80,7 +86,7 @@ static void check_case(Geom p, int in_layout, int out_layout, int grid_override,
       const int oy0 = iy0 / STRIDE, ox0 = ix0 / STRIDE;
       const int imgs_here = std::min(p.IMGS, p.B - img0);
       REQUIRE(imgs_here > 0, "%s: tile beyond the batch", what);
-      staged.assign((size_t)p.IMGS * p.HR * p.HP * 4, 0);   // [LDS pixel][16-byte slot]: filled from the tensor?
+      staged.assign((size_t)win_px * 4, 0);   // [LDS pixel][16-byte slot]: filled from the tensor?
       for (int tid = 0; tid < threads; ++tid) {
         const int* row = &ht.lane[(size_t)tid * ht.lane_stride];
         const unsigned mk = ht.mask[(size_t)mrow * threads + tid];
@@ -111,7 +117,8 @@ static void check_case(Geom p, int in_layout, int out_layout, int grid_override,
               const int64_t pxb = (int64_t)p.Cin * ESZ;
               sy = r / (p.Wi * pxb); sx = (r % (p.Wi * pxb)) / pxb; sch = ((r % pxb) / 64); sslot = (r % 64) / 16;
             }
-            const int limg = px / (p.HR * p.HP), lr = px % (p.HR * p.HP);
+            const int limg = px / p.IP, lr = px % p.IP;
+            REQUIRE(lr < p.HR * p.HP, "%s: a gap pixel of the window is staged", what);
             const int hy = lr / p.HP, c = lr % p.HP;
             const int hx = STRIDE == 2 ? 2 * (c % p.HPH) + c / p.HPH : c;
             REQUIRE(simg == img0 + limg && sy == iy0 + hy - 1 && sx == ix0 + hx - 1 && sch == ch, "%s: window piece lands on the wrong pixel", what);
@@ -163,6 +170,35 @@ static void check_case(Geom p, int in_layout, int out_layout, int grid_override,
           }
         }
       }
+      // every tap of every existing output pixel reads INSIDE the window, on a pixel staged from the tensor exactly when the tap is inside
+      // the image and on a zero (unstaged) pixel otherwise -- this is what makes shared halo rows / columns of fit tiles legal
+      if (STRIDE == 1 && !HALF)
+        for (int tid = 0; tid < threads; tid += 1) {
+          if ((tid & 63) >= 32) continue;   // lanes l and l + 32 own the same pixel
+          const int* row = &ht.lane[(size_t)tid * ht.lane_stride];
+          const unsigned mk = ht.mask[(size_t)mrow * threads + tid];
+          for (int nt = 0; nt < NT; ++nt) {
+            if (!((mk >> (16 + nt)) & 1u)) continue;
+            const int base_lin = row[NT + nt];
+            // recover (img, ty, tx) of the pixel from its output offset (dense NHWC / blocked maps only)
+            if (!(p.o_px == p.out_px && p.o_base == 0)) continue;
+            const int64_t e = (int64_t)out_off + row[nt];
+            int64_t pix;
+            if (out_layout == 2) pix = (e / p.o_img) * p.Ho * p.Wo + ((e % p.o_img) % ((int64_t)p.Ho * p.Wo * 16)) / 16;
+            else if (out_layout == 1) pix = (e / p.o_img) * p.Ho * p.Wo + ((e % p.o_img) % ((int64_t)p.Ho * p.Wo * 32)) / 32;
+            else pix = e / p.Cout;
+            const int oy = (int)((pix % ((int64_t)p.Ho * p.Wo)) / p.Wo), ox = (int)(pix % p.Wo);
+            for (int kh = 0; kh < 3; ++kh)
+              for (int kw = 0; kw < 3; ++kw) {
+                const int lin = base_lin + kh * p.HP + kw;
+                REQUIRE(lin >= 0 && lin < win_px, "%s: tap (%d, %d) of pixel (%d, %d) reads window index %d of %d", what, kh, kw, oy, ox, lin, win_px);
+                const int iy = oy + kh - 1, ix = ox + kw - 1;
+                const bool inside = iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                REQUIRE((staged[(size_t)lin * 4] != 0) == inside, "%s: tap (%d, %d) of pixel (%d, %d): window index %d is %s but the tap is %s the image",
+                        what, kh, kw, oy, ox, lin, staged[(size_t)lin * 4] ? "data" : "zero", inside ? "inside" : "outside");
+              }
+          }
+        }
       // every in-image pixel of the window must have all four slots staged from the tensor
       for (int limg = 0; limg < imgs_here; ++limg)
         for (int hy = 0; hy < p.HR; ++hy)
@@ -170,7 +206,7 @@ static void check_case(Geom p, int in_layout, int out_layout, int grid_override,
             const int iy = iy0 + hy - 1, ix = ix0 + hx - 1;
             if (iy < 0 || iy >= p.Hi || ix < 0 || ix >= p.Wi) continue;
             const int c = STRIDE == 2 ? (hx & 1) * p.HPH + (hx >> 1) : hx;
-            const size_t px = ((size_t)limg * p.HR + hy) * p.HP + c;
+            const size_t px = (size_t)limg * p.IP + (size_t)hy * p.HP + c;
             for (int sl = 0; sl < 4; ++sl)
               REQUIRE(staged[px * 4 + sl], "%s: in-image window pixel (%d, %d, %d) slot %d is padded", what, limg, hy, hx, sl);
           }
@@ -208,12 +244,12 @@ static void sweep_layer(int B, int Hi, int cin, int cout, int stride, bool block
     check_case<2, 1, 8, ESZ, 1>(p, in_l, out_l, 0, what.c_str());
     return;
   }
-  Cand c[4];
+  Cand c[kMaxCands];
   const int nc = stride1_candidates(p.Ho, p.Wo, c);
   const Cand picked = pick_stride1(B, p.Ho, p.Wo, cout, min_tiles);
   for (int i = 0; i < nc; ++i) {   // ALL candidates, not only the picked one
     set_stride1_geometry(p, c[i], p.Ho, p.Wo);
-    const std::string w2 = what + " cand" + std::to_string(i) + (c[i].th == picked.th && c[i].tw == picked.tw && c[i].imgs == picked.imgs ? "*" : "");
+    const std::string w2 = what + " cand" + std::to_string(i) + (c[i].fit ? "fit" : "") + (c[i].th == picked.th && c[i].tw == picked.tw && c[i].imgs == picked.imgs ? "*" : "");
     if (c[i].variant == 0) check_case<1, 2, 8, ESZ, 2>(p, in_l, out_l, 0, w2.c_str());
     else if (c[i].variant == 1) check_case<1, 1, 8, ESZ, 2>(p, in_l, out_l, 0, w2.c_str());
     else check_case<1, 1, 8, ESZ, 1>(p, in_l, out_l, 0, w2.c_str());
@@ -310,6 +346,38 @@ int main(int argc, char** argv) {
       HostTables ht;
       const char* why = build_tables<1, 2, 8, 2, 2, Geom>(p, 1, 0, &ht);
       REQUIRE(why && std::string(why).find("64 KiB") != std::string::npos, "oversized window: %s", why ? why : "(accepted)");
+      ++g_cases;
+    }
+  }
+  // ---- fit tiles: bank-conflict census of the dealt lane order (a 16-lane service group reads conflict-free when its pixels have 16
+  // different window indices mod 16)
+  {
+    struct F { int imgs, th, tw, ip, hp, ntile32, max_conflict_groups; const char* name; };
+    for (const F& f : {F{10, 7, 7, 67, 8, 16, 0, "7x7 x10"}, F{5, 7, 7, 67, 8, 8, 8, "7x7 x5"}, F{5, 7, 14, 135, 15, 16, 0, "7x14 x5"}}) {
+      const std::vector<int> slot = deal_fit_pixels(f.imgs, f.th, f.tw, f.ip, f.hp, f.ntile32);
+      std::set<int> seen;
+      int conflict_groups = 0;
+      static const int ga[16] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
+      for (int t = 0; t < f.ntile32; ++t)
+        for (int half = 0; half < 2; ++half) {
+          int cnt[16] = {0};
+          bool in_a[32] = {false};
+          for (int k = 0; k < 16; ++k) in_a[ga[k]] = true;
+          for (int ll = 0; ll < 32; ++ll) {
+            if (in_a[ll] != (half == 0)) continue;
+            const int q = slot[(size_t)t * 32 + ll];
+            if (q < 0) continue;
+            REQUIRE(seen.insert(q).second, "%s: pixel %d dealt twice", f.name, q);
+            const int img = q / (f.th * f.tw), ty = (q % (f.th * f.tw)) / f.tw, tx = q % f.tw;
+            ++cnt[(img * f.ip + ty * f.hp + tx) & 15];
+          }
+          bool c2 = false;
+          for (int r = 0; r < 16; ++r) { REQUIRE(cnt[r] <= 2, "%s: %d-way conflict", f.name, cnt[r]); c2 |= cnt[r] > 1; }
+          conflict_groups += c2;
+        }
+      REQUIRE((int)seen.size() == f.imgs * f.th * f.tw, "%s: %zu of %d pixels dealt", f.name, seen.size(), f.imgs * f.th * f.tw);
+      REQUIRE(conflict_groups <= f.max_conflict_groups, "%s: %d service groups with a 2-way conflict (bound %d)", f.name, conflict_groups, f.max_conflict_groups);
+      printf("fit %s: %d of %d service groups with a 2-way bank conflict\n", f.name, conflict_groups, 2 * f.ntile32);
       ++g_cases;
     }
   }

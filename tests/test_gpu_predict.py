@@ -221,8 +221,8 @@ def test_bf16_pipeline_class_map_gate(dev):
     assert agree >= 0.999, f"class-map agreement {agree}"
 
 
-@pytest.mark.parametrize("micro_batch", [1024, None])
-def test_full_size_fused_bf16_properties(dev, micro_batch):
+@pytest.mark.parametrize("P,S,micro_batch", [(256, 256, 1024), (256, 256, None), (224, 112, None)])
+def test_full_size_fused_bf16_properties(dev, golden_meta, P, S, micro_batch):
     """BASELINE configs[2] at full size (50 000^2, 38 416 tiles, bf16, fused gather + forward; micro-batch 1024 and None = the
     library default bench.py times: 10 equal launches of 3 842 tiles, 2 GB per layer-1 activation -- VERDICT r3 missing #1):
     size-independent properties instead of an oracle run --
@@ -231,27 +231,35 @@ def test_full_size_fused_bf16_properties(dev, micro_batch):
         checked against the CPU oracle, tests/test_gpu_resnet.py);
       * the padded duplicates of the corner tile carry the corner's logits;
       * the int64 class map equals the ORACLE's ordered accumulate + argmax (oracle/tiling.py) of the GPU's logits on the
-        whole 3125 x 3125 canvas, bit for bit."""
+        whole 3125 x 3125 canvas, bit for bit.
+    (224, 112) is the reference's OWN geometry (examples/predict_full_patched.py:157-167, config.yaml:23): 198 916 tiles, every canvas cell
+    covered by up to four tiles; its grid is pinned to the reference's `_create_batched_coords` by the fixture hash."""
+    import hashlib
     from deephisto_amd import tiles
     from deephisto_amd.examples.predict_full_patched import predict_full_patched
     from deephisto_amd.models.patch_cls_simple.model import get_model
     from deephisto_amd.patch_samplers.full_samplers import FullImageDenseSampler
-    side, P = 50000, 256
+    side = 50000
     slide = tiles.synth_slide(side, side, 0, dev)
     oracle = oracle_net.seeded_model(31, 5, perturb_bn=True).eval()
     model = get_model(5, "bf16")
     model.load_state_dict(oracle.state_dict())
     model.to(dev).eval()
-    smp = FullImageDenseSampler(slide, layer=1, patch_size=P, batch_size=64, stride=P, device=dev)
+    smp = FullImageDenseSampler(slide, layer=1, patch_size=P, batch_size=64, stride=S, device=dev)
     cmap, logits = predict_full_patched(smp, model, 5, downscale=16, micro_batch=micro_batch, return_logits=True)
     o = smp.origins
-    assert smp.n_tiles == 38416 and len(o) == 601 * 64 and tuple(logits.shape) == (601 * 64, 5)
+    nu = {256: 38416, 224: 198916}[P]
+    npad = -(-nu // 64) * 64
+    assert smp.n_tiles == nu and len(o) == npad and tuple(logits.shape) == (npad, 5)
+    fix = [g for g in golden_meta["grids"].values() if (g["h"], g["w"], g["patch"], g["stride"], g["batch"]) == (side, side, P, S, 64)]
+    assert fix and hashlib.sha256(np.ascontiguousarray(o).tobytes()).hexdigest() == fix[0]["sha256_int32_yx_padded"]   # the reference's grid
     rng = np.random.default_rng(0)
-    idx = np.unique(np.concatenate([[0, 194, 195, 38024, 38025, 38219, 38220, 38414, 38415, 38416, 38463],
-                                    rng.integers(0, 38416, 53)]))
+    nx = {256: 195, 224: 445}[P]           # interior columns per row of the grid: section boundaries of the reference's order
+    idx = np.unique(np.concatenate([[0, nx - 1, nx, nu - 2 * nx - 2, nu - 2 * nx - 1, nu - nx - 2, nu - nx - 1, nu - 2, nu - 1, nu, npad - 1],
+                                    rng.integers(0, nu, 53)]))
     small = model.forward_tiles(slide, torch.from_numpy(o[idx]).to(dev), P)
     assert torch.equal(small, logits[torch.from_numpy(idx).to(dev)]), "whole-slide logits differ from a small launch of the same tiles"
-    assert torch.equal(logits[38416:], logits[38415:38416].expand(48, -1))          # corner padding duplicates
+    assert torch.equal(logits[nu:], logits[nu - 1:nu].expand(npad - nu, -1))          # corner padding duplicates
     lg = logits.cpu().numpy()
     assert np.isfinite(lg).all()
     canvas = tiling.accumulate_logits(side, side, 5, 16, P, o, lg)

@@ -149,14 +149,18 @@ def test_model_errors(dev):
         m(torch.zeros(1, 4, 64, 64, device=dev))
 
 
-@pytest.mark.parametrize("dtype,P,n", [("bf16", 256, 70), ("bf16", 224, 300), ("f32", 128, 130), ("bf16", 256, 4096), ("f32", 256, 1024)])
+@pytest.mark.parametrize("dtype,P,n", [("bf16", 256, 70), ("bf16", 224, 300), ("f32", 128, 130), ("bf16", 256, 4096), ("f32", 256, 1024),
+                                         ("bf16", 224, 4096), ("f32", 224, 1024)])
 def test_large_launch_matches_small_launches(dev, dtype, P, n):
     """Launches with >= 256 conv tiles use the XCD-grouped persistent schedule (several iterations per workgroup,
     the last one partial, resident weights, 512-pixel tiles); launches of a few tiles use one tile per workgroup and
     smaller tile variants.  The per-tile arithmetic is the same, so the logits must be IDENTICAL -- and the small
     launches are the ones checked against the CPU oracle above.  n = 4 096 at P = 256 in bf16 is the library's maximum: a
     64 x 64 x 64-channel map is exactly 2^31 bytes and the schedule tables carry byte offsets as 32-bit words (unsigned in the
-    kernel; tests/test_conv_tables_host.py sweeps the host tables under sanitizers); n = 1 024 is the float32 maximum."""
+    kernel; tests/test_conv_tables_host.py sweeps the host tables under sanitizers); n = 1 024 is the float32 maximum.
+    P = 224 at n = 4 096 / 1 024 (round 5): the reference's own patch size at the launch size bench.py's `p224` object is timed at -- its
+    14 x 14 and 7 x 7 maps run on the FIT tiles there (five 7 x 14 half-images / ten whole 7 x 7 images per 512 slots, shared zero halos,
+    lanes dealt to pixels by the host: conv3_tables_host.h), the small launches on power-of-two tiles."""
     from deephisto_amd import tiles
     oracle = oracle_net.seeded_model(31, 5, perturb_bn=True).eval()
     model = _hip_model(oracle, dev, dtype)
