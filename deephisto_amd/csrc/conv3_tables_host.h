@@ -66,6 +66,15 @@ inline int stride1_candidates(int Ho, int Wo, Cand (&c)[kMaxCands], bool fit = t
     c[nc++] = {8, 8, 2, 12, 2};
     return nc;
   }
+  if (fit && Ho == 8 && Wo == 8) {
+    // whole 8 x 8 images with shared zero halos (pitch 9, 9 rows per image), segments 82 pixels apart (every residue mod 16 exactly 32
+    // times: conflict-free): EIGHT images = 512 slots on the NT = 2 variant -- the power-of-two list runs 8 x 8 maps as four images
+    // per 256-slot tile (NT = 1: a 36 KiB weight slab per 256 pixels instead of per 512; layer 4 of a 256-pixel patch, cin = 512)
+    c[nc++] = {8, 8, 8, 9, 0, 9, 7 * 82 + 81 + 10 - 8 * 81, 1, 82};
+    c[nc++] = {8, 8, 4, 12, 1};
+    c[nc++] = {8, 8, 2, 12, 2};
+    return nc;
+  }
   if (Wo > 16) {
     // 16x32 or 8x64 output pixels, whichever wastes fewer tile slots (56x56: 77 % vs 88 % useful)
     const int slots_a = ((Ho + 15) / 16) * ((Wo + 31) / 32), slots_b = ((Ho + 7) / 8) * ((Wo + 63) / 64);

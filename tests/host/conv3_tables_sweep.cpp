@@ -353,7 +353,7 @@ int main(int argc, char** argv) {
   // different window indices mod 16)
   {
     struct F { int imgs, th, tw, ip, hp, ntile32, max_conflict_groups; const char* name; };
-    for (const F& f : {F{10, 7, 7, 67, 8, 16, 0, "7x7 x10"}, F{5, 7, 7, 67, 8, 8, 8, "7x7 x5"}, F{5, 7, 14, 135, 15, 16, 0, "7x14 x5"}}) {
+    for (const F& f : {F{10, 7, 7, 67, 8, 16, 0, "7x7 x10"}, F{5, 7, 7, 67, 8, 8, 8, "7x7 x5"}, F{5, 7, 14, 135, 15, 16, 0, "7x14 x5"}, F{8, 8, 8, 82, 9, 16, 0, "8x8 x8"}}) {
       const std::vector<int> slot = deal_fit_pixels(f.imgs, f.th, f.tw, f.ip, f.hp, f.ntile32);
       std::set<int> seen;
       int conflict_groups = 0;
