@@ -14,7 +14,7 @@ ordered accumulate + argmax produce the int64 class map.  The slide is generated
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task description) with extra objects:
-`roofline` for the dominant kernel (3x3 stride-1 conv, MFMA-bound) timed live with HIP
+`roofline` for the dominant kernel (3x3 stride-1 conv on 512-pixel tiles: layers 1-4, MFMA-bound) timed live with HIP
 events on the launch stream; `cpu_baseline`: the oracle's CPU restatement of the reference
 path (NumPy tiling + torch-CPU ResNet-18 fp32) timed on a bounded sample; and, at N = 1,
   `f32`        the same slide in float32 (the mode of north_star's "logits within 1e-4"), its own roofline vs 157.3 TF;
@@ -493,8 +493,7 @@ def main():
         achieved = (k_flops_v / (k_ms_v * 1e-3)) / 1e12 if k_ms_v > 0 else 0.0
         flop_tile = FLOP_PER_TILE_256 * (args.patch / 256.0) ** 2
         traffic = None   # HBM bytes per launch of the dominant kernel: from the committed PMC passes (rocprofv3
-        pmc = next((q for q in (REPO / "profiles" / "r04_pmc_dominant_kernel.json", REPO / "profiles" / "r03_pmc_dominant_kernel.json", REPO / "profiles" / "r02_pmc_dominant_kernel.json",
-                                REPO / "profiles" / "r01_pmc_dominant_kernel.json") if q.exists()), REPO / "none")   # cannot run inside the timed process)
+        pmc = next((q for q in (REPO / "profiles" / f"r0{r}_pmc_dominant_kernel.json" for r in (5, 4, 3, 2, 1)) if q.exists()), REPO / "none")   # cannot run inside the timed process)
         if pmc.exists() and args.dtype == "bf16" and args.patch == 256:
             doc = json.loads(pmc.read_text())
             if doc.get("micro_batch") == args.micro_batch:
@@ -514,7 +513,7 @@ def main():
                        "n_tiles": n_tiles, "n_classes": 5,
                        "parallelism": f"tile-range shard x{world}" + (" + RCCL all-gather of logits" if world > 1 else "")},
             "model_tflops": value * flop_tile / 1e12,
-            "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<{args.dtype}, stride 1, NT=2, 8 waves> (layers 1-3, 10 of 20 convs; two instantiations: layer 1 keeps its weights resident in LDS)",
+            "roofline": {"bound": "mfma", "kernel": f"conv3x3_kernel<{args.dtype}, stride 1, NT=2, 8 waves> (every stride-1 3x3 conv of layers 1-4: 13 of 20 convs, 84 % of the FLOPs; two instantiations: layer 1 keeps its weights resident in LDS)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_source": (f"profiles/{pmc.name} (two separate rocprofv3 --pmc passes of this command, FETCH_SIZE x 2 + "

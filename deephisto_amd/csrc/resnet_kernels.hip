@@ -871,7 +871,7 @@ int launch_conv3x3(const ConvLayer& L, const void* in, const void* res, void* ou
     p.stamps = g_stamps_dev + 8 * row;
   }
   bool sample = false;
-  // sampled: the dominant variant only (stride 1, 512-pixel tiles: layers 1-3)
+  // sampled: the dominant variant only (stride 1, 512-slot tiles: layers 1-3, and since round 5 layer 4 on its fit tiles)
   auto maybe_sample = [&](bool dominant) -> int {
     if (dominant && g_prof.on && g_prof.used + 2 <= g_prof.ev.size() && (g_prof.counter++ % g_prof.every) == 0) {
       sample = true;

@@ -2,7 +2,7 @@
 """Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/*_pmc_dominant_kernel.json.
 
 Tooling, not product.  Usage: pmc_summary.py <fetch_dir> <write_dir> <micro_batch> <out.json> [tiles_per_launch]
-The dominant kernel is conv3x3_kernel<bf16, stride 1, NT=2, 8 waves> (layers 1-3 of ResNet-18 at
+The dominant kernel is conv3x3_kernel<bf16, stride 1, NT=2, 8 waves> (every stride-1 3x3 conv, layers 1-4, of ResNet-18 at
 256x256 tiles).  gfx950 corrections follow MI355X_MICROARCH.md (HBM / rocprofv3 section): counters
 are in KiB; FETCH_SIZE under-counts 16-B-per-lane streaming reads by 2x; WRITE_SIZE is taken as is.
 """
@@ -33,12 +33,13 @@ def avg_counter(path, name):
 
 
 def algorithmic_bytes(mb):
-    """input + output (+ residual) of the 10 launches of this variant per forward, bf16 NHWC, no halo."""
+    """input + output (+ residual) of the 13 launches of this variant per forward, bf16, no halo (round 5: layer 4's 8 x 8 maps run on
+    this variant too -- eight whole images per 512-slot tile -- so it covers every stride-1 3x3 conv of the network)."""
     tot = 0
-    for hw, c, n, n_res in ((64, 64, 4, 2), (32, 128, 3, 2), (16, 256, 3, 2)):
+    for hw, c, n, n_res in ((64, 64, 4, 2), (32, 128, 3, 2), (16, 256, 3, 2), (8, 512, 3, 2)):
         act = mb * hw * hw * c * 2
         tot += n * 2 * act + n_res * act + n * 9 * c * c * 2
-    return tot / 10
+    return tot / 13
 
 
 def main(fetch_dir, write_dir, mb, out, tiles=None):
@@ -55,8 +56,8 @@ def main(fetch_dir, write_dir, mb, out, tiles=None):
                       "(MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE taken as is; units KiB",
         "traffic_bytes_per_launch": (2 * fetch + write) * 1024,
         "algorithmic_bytes_per_launch": algorithmic_bytes(tiles),
-        "note": "algorithmic = input + output (+ residual on 6 of 10) + weights, no halo, averaged over the 10 "
-                "launches per forward of this variant (layer1 x4, layer2 x3, layer3 x3)",
+        "note": "algorithmic = input + output (+ residual on 8 of 13) + weights, no halo, averaged over the 13 "
+                "launches per forward of this variant (layer1 x4, layer2 x3, layer3 x3, layer4 x3)",
     }
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc, indent=1))

@@ -3,7 +3,7 @@
 # default bench line, rocprofv3 kernel stats of the same command, the two --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs,
 # kernel trace only), per-layer table, MFMA utilisation per layer (SQ counters), conv phase stamps, training kernel stats.
 set -e
-RND=${1:-r04}
+RND=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; P=$O/profiles_$RND; mkdir -p $P
 cd $R
@@ -14,6 +14,11 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats -o st -- p
 cp $(find $O/prof_stats -name 'st_kernel_stats.csv' | head -1) $P/${RND}_bench_kernel_stats.csv
 python3 tools/trace_summary.py $O/prof_stats 3968 > $P/${RND}_bench_per_layer.txt
 echo "stats done"
+# the reference's own geometry (224 / 112): kernel stats of the same command the line's `p224` object times
+rm -rf $O/prof_stats224
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats224 -o st -- python3 bench.py --patch 224 --stride 112 --steps 1 --warmup 1 --no-cpu-baseline --no-extra-legs --train-steps 0 > $O/bench_prof224.json 2> $O/bench_prof224.err
+cp $(find $O/prof_stats224 -name 'st_kernel_stats.csv' | head -1) $P/${RND}_bench_p224_kernel_stats.csv
+echo "p224 stats done"
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-legs --train-steps 0 > $O/pmc_f.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-legs --train-steps 0 > $O/pmc_w.log 2>&1
 python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 4096 $P/${RND}_pmc_dominant_kernel.json 3842 > /dev/null
