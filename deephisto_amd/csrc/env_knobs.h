@@ -21,7 +21,6 @@
   X(DH_T2_SIDE, 1, 0, 1, "create", "bf16 training engine: weight gradients, Adam and re-pack on a low-priority side stream")                       \
   X(DH_T2_JOIN, 1, 0, 1, "create", "bf16 engine: downsample branch's BN applied inside the join BN's pass (bit-identical either way)")            \
   X(DH_T2_FOLD, 1, 0, 1, "create", "bf16 engine: BN finalize folded into channel-sliced consumers on small maps (bit-identical either way)")      \
-  X(DH_T2_STEM_SWEEP, 1, 0, 1, "load", "bf16 engine: stem backward as ONE sweep (weight gradient from the linearity of the BN backward, no dZ tensor); 0 = reduce / apply / wgrad passes")   \
   X(DH_T2_FOLD_ROWS, 16384, 0, 1 << 24, "load", "bf16 engine: largest map (rows = B*H*W) that takes the folded BN path")                          \
   X(DH_G2_NSTAGE, 0, 0, 3, "load", "bf16 1x1 GEMM: LDS ring depth (0 = automatic: 2, or 3 from K >= DH_G2_NS3_K)")                                 \
   X(DH_G2_NS3_K, 512, 64, 1 << 20, "load", "bf16 1x1 GEMM: K from which the ring runs three stages deep")                                          \

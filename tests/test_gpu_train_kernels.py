@@ -479,77 +479,6 @@ def test_bn2_pool_fused_stem_tail_bf16(dev, B, H, C):
     assert _rel(got, want) <= 3e-3
 
 
-@pytest.mark.parametrize("B,P", [(3, 224), (5, 64), (2, 256), (64, 224)])
-def test_stem_backward_one_sweep_bf16(dev, B, P):
-    """Round 5: the bf16 engine's stem backward as ONE sweep (csrc/train2_kernels.inc, stem_bwd_sweep_bf16_kernel): conv1 has no data
-    gradient, so its weight gradient is taken from the linearity  dW = a (G - s1/N X1 - s2/N H)  of the BN backward instead of from a dZ
-    tensor: G = sum g x'', H = sum xhat x'' on the bf16 MFMA (x'' = x - m_c, zero padding -> -m_c), s1 / s2 / s3 the BN sums of the same pass.
-    (1) against the same formula in float64 on the SAME rounded operands (g, xhat, x'' as bf16; the device's recorded maxima, saved mean /
-    invstd and m_c): 2e-4 -- what is left is float32 accumulation of ~10^5 .. 10^6 products per element; (2) against float64 autograd of the
-    whole chain (BN batch statistics -> ReLU -> max-pool gradient scattered to the recorded maxima -> conv weight gradient) on unrounded
-    operands: 2e-2, the level of one bf16 rounding per MFMA operand (the unfused path rounded dZ and x the same way); dgamma / dbeta 1e-5;
-    (3) two runs give the same bits."""
-    from deephisto_amd._lib import check, lib
-    g = torch.Generator().manual_seed(B * P + 11)
-    Hc, Hp, C = P // 2, P // 4, 64
-    z = _bf(torch.randn(B, Hc, Hc, C, generator=g) * (torch.rand(C, generator=g) + 0.5) + torch.randn(C, generator=g) * 0.5)
-    gamma = torch.rand(C, generator=g) + 0.5
-    beta = torch.randn(C, generator=g) * 0.3
-    dpool = _bf(torch.randn(B, Hp, Hp, C, generator=g) * 1e-3)
-    x = torch.rand(B, 3, P, P, generator=g) * torch.tensor([1.0, 0.7, 0.4]).view(1, 3, 1, 1) + torch.tensor([0.0, 0.2, 0.5]).view(1, 3, 1, 1)
-    zd, gd, bd = z.to(dev).bfloat16().contiguous(), gamma.to(dev), beta.to(dev)
-    dpd, xd = dpool.to(dev).bfloat16().contiguous(), x.to(dev).contiguous()
-    outs = []
-    for _ in range(2):
-        dw = torch.empty(64, 3, 7, 7, device=dev)
-        dgam, dbet, mean, invstd = (torch.empty(C, device=dev) for _ in range(4))
-        xmean = torch.empty(3, device=dev)
-        idx = torch.empty(B, Hp, Hp, C, dtype=torch.uint8, device=dev)
-        check(lib().dh_debug_stem_bwd_bf16(zd.data_ptr(), gd.data_ptr(), bd.data_ptr(), dpd.data_ptr(), xd.data_ptr(), dw.data_ptr(), dgam.data_ptr(),
-                                           dbet.data_ptr(), mean.data_ptr(), invstd.data_ptr(), xmean.data_ptr(), idx.data_ptr(), B, P, None), "stem bwd")
-        outs.append((dw, dgam, dbet, mean, invstd, xmean, idx))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-    dw, dgam, dbet, mean, invstd, xmean, idx = (t.cpu() for t in outs[0])
-    assert float((xmean.double() - x.double().mean((0, 2, 3))).abs().max()) <= 1e-6
-    # ---- float64 autograd of the whole chain, pooled gradient scattered to the DEVICE's recorded maxima
-    z64 = z.double().requires_grad_(True)
-    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
-    mu, var = z64.mean((0, 1, 2)), z64.var((0, 1, 2), unbiased=False)
-    y64 = torch.relu((z64 - mu) / torch.sqrt(var + 1e-5) * g64 + b64)
-    ii = idx.long()
-    bb, oy, ox, cc = torch.meshgrid(torch.arange(B), torch.arange(Hp), torch.arange(Hp), torch.arange(C), indexing="ij")
-    iy, ix = 2 * oy + ii // 3 - 1, 2 * ox + ii % 3 - 1
-    dY = torch.zeros(B, Hc, Hc, C, dtype=torch.float64)
-    dY.index_put_((bb.reshape(-1), iy.reshape(-1), ix.reshape(-1), cc.reshape(-1)), dpool.double().reshape(-1), accumulate=True)
-    (y64 * dY).sum().backward()
-    dz64 = z64.grad.permute(0, 3, 1, 2).contiguous()                      # [B, 64, Hc, Hc]
-    want_true = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), dz64, stride=2, padding=3)
-    assert _rel(dgam, g64.grad) <= 1e-5 and _rel(dbet, b64.grad) <= 1e-5
-    assert _rel(dw, want_true) <= 2e-2, _rel(dw, want_true)
-    # ---- the kernel's own formula in float64 on the same rounded operands
-    mask = (y64.detach() > 0)
-    gg = torch.where(mask, dY, torch.zeros_like(dY))                     # float64 sums of <= 4 bf16 pooled gradients, masked
-    xh32 = (z.float() - mean.view(1, 1, 1, C)) * invstd.view(1, 1, 1, C)  # float32, the kernel's two operations
-    s1, s2, s3 = gg.sum((0, 1, 2)), (gg * xh32.double()).sum((0, 1, 2)), xh32.double().sum((0, 1, 2))
-    gb, hb = _bf(gg.float()).double().permute(0, 3, 1, 2).contiguous(), _bf(xh32).double().permute(0, 3, 1, 2).contiguous()
-    mc = xmean.view(1, 3, 1, 1)
-    xpp = torch.empty(B, 3, P + 6, P + 6)
-    xpp[:] = _bf(0.0 - mc.expand(B, 3, 1, 1)).expand(B, 3, P + 6, P + 6)    # zero padding, centred: bf16(0 - m_c)
-    xpp[:, :, 3:P + 3, 3:P + 3] = _bf(x - mc)
-    G = torch.nn.grad.conv2d_weight(xpp.double(), (64, 3, 7, 7), gb, stride=2, padding=0)
-    H = torch.nn.grad.conv2d_weight(xpp.double(), (64, 3, 7, 7), hb, stride=2, padding=0)
-    N = float(B * Hc * Hc)
-    xz = torch.zeros(B, 3, P + 6, P + 6, dtype=torch.float64)
-    xz[:, :, 3:P + 3, 3:P + 3] = x.double()
-    X1 = torch.nn.grad.conv2d_weight(xz, (1, 3, 7, 7), torch.ones(B, 1, Hc, Hc, dtype=torch.float64), stride=2, padding=0)[0]   # [3, 7, 7]
-    X1c = X1 - xmean.double().view(3, 1, 1) * N
-    a = (gamma.double() * invstd.double()).view(64, 1, 1, 1)
-    want = a * (G - (s1 / N).view(64, 1, 1, 1) * X1c.view(1, 3, 7, 7)
-                - (s2 / N).view(64, 1, 1, 1) * (H + xmean.double().view(1, 3, 1, 1) * s3.view(64, 1, 1, 1)))
-    assert _rel(dw, want) <= 2e-4, _rel(dw, want)
-
-
 def test_upsample2_add_and_avgpool_fc_dgrad_bf16(dev):
     from deephisto_amd._lib import check, lib
     g = torch.Generator().manual_seed(77)
