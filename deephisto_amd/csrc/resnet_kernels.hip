@@ -1516,6 +1516,7 @@ extern "C" int dh_debug_stamps(int32_t enable, unsigned long long* out64_host) {
   return DH_OK;
 }
 
+#include "gemm1x1_f32.inc"
 #include "train.inc"
 #include "train2_kernels.inc"
 #include "wgrad_ring.inc"
