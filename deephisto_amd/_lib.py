@@ -99,7 +99,6 @@ DEBUG_SIGNATURES = {
     "dh_debug_bn_f32": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "dh_debug_maxpool_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_bn_pool_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
-    "dh_debug_stem_bwd_f32": (C.c_int, [_p] * 9 + [_i32, _i32, _p]),
     "dh_debug_stamps": (C.c_int, [_i32, _p]),
     "dh_debug_env_knobs": (C.c_int, [C.c_char_p, _i64]),
 }

@@ -17,7 +17,6 @@
   X(DH_CONV_S2_WIDE, 1, 0, 1, "load", "bf16 inference: 1 = wide stride-2 + downsample kernel (128 couts x 256 pixels), 0 = 128-pixel kernel")      \
   X(DH_CONV_FIT, 1, 0, 1, "load", "3x3 stride-1 convs on 7x7 / 14x14 maps: 1 = fit tiles (ten 7x7 images / five 7x14 half-images per 512 slots), 0 = power-of-two tiles")   \
   X(DH_T1_SIDE, 1, 0, 1, "create", "float32 training engine: weight gradients on a low-priority side stream")                                     \
-  X(DH_T1_STEM_SWEEP, 1, 0, 1, "load", "float32 engine: stem backward as ONE sweep (weight gradient from the linearity of the BN backward, no dZ tensor); 0 = reduce / apply / wgrad passes")   \
   X(DH_WGRAD3_WGS, 0, 0, 256, "load", "float32 3x3 weight gradient: workgroups per launch (0 = 224 with the side stream, else 256)")              \
   X(DH_T2_SIDE, 1, 0, 1, "create", "bf16 training engine: weight gradients, Adam and re-pack on a low-priority side stream")                       \
   X(DH_T2_JOIN, 1, 0, 1, "create", "bf16 engine: downsample branch's BN applied inside the join BN's pass (bit-identical either way)")            \

@@ -98,11 +98,6 @@ int dh_debug_maxpool_f32(const float* x_dev, float* y_dev, const float* dy_dev, 
 int dh_debug_bn_pool_f32(const float* z_dev, const float* gamma_dev, const float* beta_dev, float* pooled_dev, uint8_t* idx_dev,
                          const float* dpool_dev, float* dz_dev, float* dgamma_dev, float* dbeta_dev, int32_t B, int32_t Hi, int32_t Wi,
                          int32_t C, void* stream);
-/* dh_debug_stem_bwd_f32: the float32 engine's ONE-SWEEP stem backward (round 5: max-pool, ReLU and BN backward and conv1's weight gradient
- * without a dZ tensor; csrc/train.inc) on caller data: z [B][P/2][P/2][64], gamma / beta [64], dpool [B][P/4][P/4][64] (gradient of the
- * pooled map), x [B][3][P][P] -> dW [64][3][7][7], dgamma, dbeta [64] and the recorded first-maximum positions (idx uint8 [B][P/4][P/4][64]). */
-int dh_debug_stem_bwd_f32(const float* z_dev, const float* gamma_dev, const float* beta_dev, const float* dpool_dev, const float* x_nchw_dev,
-                          float* dw_dev, float* dgamma_dev, float* dbeta_dev, uint8_t* idx_dev, int32_t B, int32_t P, void* stream);
 /* dh_debug_stamps: switch the 3x3-conv kernel to its cycle-stamped diagnostic variant and/or read
  * (and clear) its 8x8 table of summed phase cycles; out64_host may be NULL. */
 int dh_debug_stamps(int32_t enable, unsigned long long* out64_host);

@@ -233,50 +233,6 @@ def test_bn_pool_fused_stem_tail_f32(dev, B, H, C):
 
 
 # ---- bf16 engine (train2): the GEMM-shaped kernels on their own ------------------------------------------------------
-@pytest.mark.parametrize("B,P", [(3, 224), (5, 64), (2, 96), (64, 224)])
-def test_stem_backward_one_sweep_f32(dev, B, P):
-    """Round 5: the float32 engine's stem backward as ONE sweep (csrc/train.inc, stem_bwd_sweep_f32_kernel): conv1 has no data gradient, so
-    its weight gradient is taken from the linearity  dW = a (G - s1/N X1 - s2/N H)  of the BN backward instead of from a dZ tensor -- G = sum
-    g x'', H = sum xhat x'' on the float32 MFMA (x'' = x - m_c, zero padding -> -m_c), s1 / s2 / s3 the BN sums of the same pass.  Against
-    float64 autograd of the whole chain (BN batch statistics -> ReLU -> max-pool gradient scattered to the device's recorded maxima -> conv
-    weight gradient): dW 2e-5 (float32 accumulation of ~10^5 .. 10^6 products per element; the unfused kernels are held to 1e-5 each),
-    dgamma / dbeta 1e-5; two runs give the same bits."""
-    from deephisto_amd._lib import check, lib
-    g = torch.Generator().manual_seed(B * P + 13)
-    Hc, Hp, C = P // 2, P // 4, 64
-    z = torch.randn(B, Hc, Hc, C, generator=g) * (torch.rand(C, generator=g) + 0.5) + torch.randn(C, generator=g) * 0.5
-    gamma = torch.rand(C, generator=g) + 0.5
-    beta = torch.randn(C, generator=g) * 0.3
-    dpool = torch.randn(B, Hp, Hp, C, generator=g) * 1e-3
-    x = torch.rand(B, 3, P, P, generator=g) * torch.tensor([1.0, 0.7, 0.4]).view(1, 3, 1, 1) + torch.tensor([0.0, 0.2, 0.5]).view(1, 3, 1, 1)
-    zd, gd, bd, dpd, xd = (t.to(dev).contiguous() for t in (z, gamma, beta, dpool, x))
-    outs = []
-    for _ in range(2):
-        dw = torch.empty(64, 3, 7, 7, device=dev)
-        dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
-        idx = torch.empty(B, Hp, Hp, C, dtype=torch.uint8, device=dev)
-        check(lib().dh_debug_stem_bwd_f32(zd.data_ptr(), gd.data_ptr(), bd.data_ptr(), dpd.data_ptr(), xd.data_ptr(), dw.data_ptr(), dgam.data_ptr(),
-                                          dbet.data_ptr(), idx.data_ptr(), B, P, None), "stem bwd f32")
-        outs.append((dw, dgam, dbet, idx))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-    dw, dgam, dbet, idx = (t.cpu() for t in outs[0])
-    z64 = z.double().requires_grad_(True)
-    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
-    mu, var = z64.mean((0, 1, 2)), z64.var((0, 1, 2), unbiased=False)
-    y64 = torch.relu((z64 - mu) / torch.sqrt(var + 1e-5) * g64 + b64)
-    ii = idx.long()
-    bb, oy, ox, cc = torch.meshgrid(torch.arange(B), torch.arange(Hp), torch.arange(Hp), torch.arange(C), indexing="ij")
-    iy, ix = 2 * oy + ii // 3 - 1, 2 * ox + ii % 3 - 1
-    assert int(ii.max()) <= 8 and bool(((iy >= 0) & (iy < Hc) & (ix >= 0) & (ix < Hc)).all())
-    dY = torch.zeros(B, Hc, Hc, C, dtype=torch.float64)
-    dY.index_put_((bb.reshape(-1), iy.reshape(-1), ix.reshape(-1), cc.reshape(-1)), dpool.double().reshape(-1), accumulate=True)
-    (y64 * dY).sum().backward()
-    want = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), z64.grad.permute(0, 3, 1, 2).contiguous(), stride=2, padding=3)
-    assert _rel(dgam, g64.grad) <= 1e-5 and _rel(dbet, b64.grad) <= 1e-5
-    assert _rel(dw, want) <= 2e-5, _rel(dw, want)
-
-
 def _bf(t):
     return t.bfloat16().float()
 
