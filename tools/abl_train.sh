@@ -9,7 +9,7 @@ O=gpurun_out/abl_train_$A.txt; : > $O
 cp deephisto_amd/libdeephisto_hip.so /tmp/dh_keep.so
 echo "== base" >> $O; python3 tools/train_time.py $A --steps 40 2>/dev/null >> $O
 for v in "$@"; do
-  cp deephisto_amd/libdeephisto_hip_abl$v.so deephisto_amd/libdeephisto_hip.so
+  cp deephisto_amd/libdeephisto_hip_${PFX:-abl}$v.so deephisto_amd/libdeephisto_hip.so
   echo "== -DDH_T2_ABL=$v" >> $O; python3 tools/train_time.py $A --steps 40 2>/dev/null >> $O
 done
 cp /tmp/dh_keep.so deephisto_amd/libdeephisto_hip.so
