@@ -19,7 +19,6 @@
   X(DH_T1_SIDE, 1, 0, 1, "create", "float32 training engine: weight gradients on a low-priority side stream")                                     \
   X(DH_WGRAD3_WGS, 0, 0, 256, "load", "float32 3x3 weight gradient: workgroups per launch (0 = 224 with the side stream, else 256)")              \
   X(DH_T2_SIDE, 1, 0, 1, "create", "bf16 training engine: weight gradients, Adam and re-pack on a low-priority side stream")                       \
-  X(DH_T2_OPT, 1, 0, 1, "create", "bf16 engine, fused backward + Adam: slab reduces, Adam and re-pack on their own stream behind the side stream's weight gradients") \
   X(DH_T2_JOIN, 1, 0, 1, "create", "bf16 engine: downsample branch's BN applied inside the join BN's pass (bit-identical either way)")            \
   X(DH_T2_FOLD, 1, 0, 1, "create", "bf16 engine: BN finalize folded into channel-sliced consumers on small maps (bit-identical either way)")      \
   X(DH_T2_FOLD_ROWS, 16384, 0, 1 << 24, "load", "bf16 engine: largest map (rows = B*H*W) that takes the folded BN path")                          \
