@@ -32,6 +32,7 @@ for a in resnet18 resnet18bf16 resnet50; do
   rm -rf $O/prof_train_$a
   rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_train_$a -o t -- python3 tools/train_profile.py $a > $O/train_prof_$a.log 2>&1
   cp $(find $O/prof_train_$a -name 't_kernel_stats.csv' | head -1) $P/${RND}_train_${a}_kernel_stats.csv
+  python3 tools/step_timeline.py $O/prof_train_$a $P/${RND}_timeline_${a}.txt
 done
 find $O -name '*counter_collection.csv' -size +20M -delete
 find $O -name '*kernel_trace.csv' -size +20M -delete
