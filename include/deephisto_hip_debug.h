@@ -88,6 +88,9 @@ int dh_debug_wgrad_f32(const float* dz_dev, const float* x_dev, float* dw_dev, i
 int dh_debug_stem_wgrad_f32(const float* dz_dev, const float* x_nchw_dev, float* dw_dev, int32_t B, int32_t P, void* stream);
 int dh_debug_dgrad_f32(const float* dz_dev, const float* w_dev, const float* res_dev, float* dx_dev, int32_t B, int32_t Hi,
                        int32_t Wi, int32_t cin, int32_t cout, int32_t ks, int32_t stride, void* stream);
+/* both packed operators of w[cout][cin][3][3]: the training step's sub-tile kernel (..._tile) and the element-wise kernel (..._elem) */
+int dh_debug_pack_f32(const float* w_dev, int32_t cout, int32_t cin, float* wf_tile, float* wd_tile, float* wf_elem, float* wd_elem,
+                      void* stream);
 int dh_debug_bn_f32(const float* z_dev, const float* gamma_dev, const float* beta_dev, const float* res_dev, int32_t relu,
                     float* y_dev, const float* dy_dev, float* dz_dev, float* g_dev, float* dgamma_dev, float* dbeta_dev,
                     float* stats_out_dev, int64_t rows, int32_t C, void* stream);

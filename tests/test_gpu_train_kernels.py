@@ -543,3 +543,16 @@ def test_gemm1x1_fused_bn_backward_sums(dev, M, N, K, mode):
     assert _rel(sums[:N].cpu(), s1.cpu()) <= 1e-5 and _rel(sums[N:].cpu(), s2.cpu()) <= 1e-5
     if mode == 0:
         assert int((out[msk.float() <= 0].view(torch.int16) != 0).sum()) == 0
+
+
+@pytest.mark.parametrize("cout,cin", [(64, 64), (128, 64), (128, 128), (256, 128), (512, 256), (512, 512)])
+def test_pack_f32_tiles_match_the_elementwise_form(dev, cout, cin):
+    """The float32 step re-packs its 3x3 weights after every update with a sub-tile kernel (16 couts x 64 cins x 9 taps through LDS, round 5);
+    both operators -- forward and flipped / transposed for the data gradient -- must equal the element-wise packer of the load path bit for bit."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(cout * 7 + cin)
+    w = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    outs = [torch.full((cout * cin * 9,), float("nan"), device=dev) for _ in range(4)]
+    check(lib().dh_debug_pack_f32(w.data_ptr(), cout, cin, *[o.data_ptr() for o in outs], None), "dh_debug_pack_f32")
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    assert not torch.isnan(outs[0]).any() and not torch.isnan(outs[1]).any()
