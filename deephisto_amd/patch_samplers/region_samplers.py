@@ -140,9 +140,9 @@ class RectRegionRndSampler:
             yx, lab = self.sample_origins(batch_size)
             fh = bool(flips and self._rng.random() < 0.5)
             fv = bool(flips and self._rng.random() < 0.5)
-            o_dev = up.upload(yx)
+            o_dev, lab_dev, coords = up.upload_batch(yx, lab)   # one staged copy per batch (origins, labels, float coordinates)
             x = tiles.gather_tiles_aug(self.slide, o_dev, self.patch_size, DH_LAYOUT_NCHW, dtype, fh, fv)
-            yield x, up.upload(lab), tiles.tile_coords(o_dev)
+            yield x, lab_dev, coords
 
 
 def synthetic_regions(h: int, w: int, n_classes: int = 5, per_class: int = 6, min_side: int = 300,

@@ -134,6 +134,21 @@ class PinnedUploader:
         slot[1] = ev
         return out
 
+    def upload_batch(self, origins: "np.ndarray", labels: "np.ndarray") -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """One batch's origins int32[n, 2], labels int64[n] and coordinates float32[n, 2] (= float(origins): exact, |origin| < 2^24,
+        what dh_tile_coords_f32 computes) as ONE staged copy: one copy and one event on the stream per batch instead of two copies, two
+        events and a kernel.  Returns device views (origins, labels, coords) of the one device buffer."""
+        import numpy as np
+
+        n = int(origins.shape[0])
+        assert origins.shape == (n, 2) and labels.shape == (n,)
+        buf = np.empty(24 * n, np.uint8)
+        buf[:8 * n] = np.ascontiguousarray(labels, np.int64).view(np.uint8)                       # 8-byte aligned first
+        buf[8 * n:16 * n] = np.ascontiguousarray(origins, np.int32).reshape(-1).view(np.uint8)
+        buf[16 * n:] = np.ascontiguousarray(origins, np.float32).reshape(-1).view(np.uint8)
+        dev = self.upload(buf)
+        return dev[8 * n:16 * n].view(torch.int32).reshape(n, 2), dev[:8 * n].view(torch.int64), dev[16 * n:].view(torch.float32).reshape(n, 2)
+
 
 def gather_tiles_raw(slide: torch.Tensor, origins_dev: torch.Tensor, patch: int) -> torch.Tensor:
     """float32[n, P, P, 3] of the raw 0..255 pixel values (FullImageRndSampler.generator_torch)."""

@@ -48,6 +48,27 @@ def test_region_sampler_output_contract(dev):
     assert tuple(f.shape) == (4, 3, P, P)
 
 
+def test_rect_sampler_device_batches_one_staged_copy(dev):
+    """device_batches of the rectangle sampler: origins, labels and float coordinates travel as ONE staged copy per batch (round 5); the batch must
+    equal what the same seed gives through sample_origins + the two coins + the gather kernel, labels and coordinates included."""
+    from deephisto_amd import tiles
+    from deephisto_amd._lib import DH_LAYOUT_NCHW
+    from deephisto_amd.patch_samplers.region_samplers import RectRegion, RectRegionRndSampler
+    host = synth.synth_slide(1200, 1400, 9)
+    regions = [RectRegion("TUM", 100, 200, 900, 1000), RectRegion("AT", 500, 700, 1150, 1350), RectRegion("BG", 0, 0, 300, 260)]
+    P, B = 96, 24
+    a = RectRegionRndSampler(host, regions, layer=1, patch_size=P, seed=11, device=dev)
+    b = RectRegionRndSampler(host, regions, layer=1, patch_size=P, seed=11, device=dev)
+    for x, lab, c in a.device_batches(B, 5, flips=True):
+        yx, want_lab = b.sample_origins(B)
+        fh = bool(b._rng.random() < 0.5)
+        fv = bool(b._rng.random() < 0.5)
+        want = tiles.gather_tiles_aug(a.slide, torch.from_numpy(yx).to(dev), P, DH_LAYOUT_NCHW, torch.float32, fh, fv)
+        assert torch.equal(x, want)
+        assert lab.dtype == torch.int64 and np.array_equal(lab.cpu().numpy(), want_lab)
+        assert c.dtype == torch.float32 and np.array_equal(c.cpu().numpy(), yx.astype(np.float32))
+
+
 def test_gather_aug_flips_match_torch(dev):
     from deephisto_amd import tiles
     from deephisto_amd._lib import DH_LAYOUT_NCHW, DH_LAYOUT_NHWC
