@@ -437,6 +437,9 @@ class AnnoRegionRndSampler:
         up = getattr(self, "_uploader", None)
         if up is None:
             up = self._uploader = tiles.PinnedUploader(dev, depth=8)   # non-blocking uploads (tiles.PinnedUploader)
+        if (arr[:, 0] == arr[0, 0]).all():   # the whole batch from one slide (always so with one_image_for_batch): one staged copy
+            o_dev, labels, coords = up.upload_batch(arr[:, 1:3].astype(np.int32), arr[:, 3].copy())
+            return tiles.gather_tiles_aug(self._bank.slide(int(arr[0, 0])), o_dev, ps, layout, dtype, flip_h, flip_v), labels, coords
         for j in np.unique(arr[:, 0]):
             sel = np.nonzero(arr[:, 0] == j)[0]
             o_dev = up.upload(arr[sel, 1:3].astype(np.int32))
