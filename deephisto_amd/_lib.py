@@ -97,6 +97,7 @@ DEBUG_SIGNATURES = {
     "dh_debug_stem_wgrad_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     "dh_debug_dgrad_f32": (C.c_int, [_p, _p, _p, _p] + [_i32] * 7 + [_p]),
     "dh_debug_pack_f32": (C.c_int, [_p, _i32, _i32, _p, _p, _p, _p, _p]),
+    "dh_debug_pack_bf16": (C.c_int, [_p, _i32, _i32, _p, _p, _p, _p, _p]),
     "dh_debug_bn_f32": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "dh_debug_maxpool_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "dh_debug_bn_pool_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),

@@ -22,6 +22,9 @@ int dh_train2_debug_act(dh_train2* net, const char* conv_name, int32_t what, flo
 /* test hooks of the engine's GEMM-shaped kernels on caller data (bf16 bits as uint16; synchronise; `repeat` launches for timing):
  * gemm1x1: out[M][N] = A[rows][K] . W[N][K]^T (+ res), stride 2 = row gather (b, 2 oy, 2 ox) from [B][Hi][Wi][K];
  * wgrad:   float32 dW[cout][cin][ks][ks] from x [B][Hi][Wi][cin] and dz [B][Ho][Wo][cout] (ks 1 or 3). */
+/* both bf16 operators of float32 w[cout][cin][3][3]: the engine's re-pack kernel (..._tile) and the element-wise packer (..._elem) */
+int dh_debug_pack_bf16(const float* w_dev, int32_t cout, int32_t cin, uint16_t* wf_tile, uint16_t* wd_tile, uint16_t* wf_elem,
+                       uint16_t* wd_elem, void* stream);
 int dh_debug_gemm1x1_bf16(const uint16_t* a_dev, const uint16_t* w_dev, const uint16_t* res_dev, uint16_t* out_dev, int64_t M,
                           int32_t N, int32_t K, int32_t stride, int32_t Ho, int32_t Wo, int32_t Hi, int32_t Wi, int32_t repeat,
                           void* stream);

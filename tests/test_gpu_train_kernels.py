@@ -556,3 +556,16 @@ def test_pack_f32_tiles_match_the_elementwise_form(dev, cout, cin):
     check(lib().dh_debug_pack_f32(w.data_ptr(), cout, cin, *[o.data_ptr() for o in outs], None), "dh_debug_pack_f32")
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
     assert not torch.isnan(outs[0]).any() and not torch.isnan(outs[1]).any()
+
+
+@pytest.mark.parametrize("cout,cin", [(64, 64), (128, 64), (128, 128), (256, 128), (512, 256), (512, 512)])
+def test_pack_bf16_tiles_match_the_elementwise_form(dev, cout, cin):
+    """The bf16 engine re-packs its 3x3 weights one 64 x 64 tile per workgroup through LDS: both bf16 operators must equal the element-wise
+    packer of the load path bit for bit."""
+    from deephisto_amd._lib import check, lib
+    g = torch.Generator().manual_seed(cout * 11 + cin)
+    w = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    outs = [torch.full((cout * cin * 9,), 0x7FC0, dtype=torch.int16, device=dev) for _ in range(4)]
+    check(lib().dh_debug_pack_bf16(w.data_ptr(), cout, cin, *[o.data_ptr() for o in outs], None), "dh_debug_pack_bf16")
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    assert int((outs[0] == 0x7FC0).sum()) == 0 and int((outs[1] == 0x7FC0).sum()) == 0
